@@ -1,0 +1,13 @@
+"""pytest configuration: registers the ``gpu`` marker and puts the repo root,
+the product package dir and tests/golden on sys.path."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "offlinerl-kit_amd"), os.path.join(ROOT, "tests", "golden"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")

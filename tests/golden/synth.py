@@ -1,0 +1,189 @@
+"""Deterministic synthetic inputs shared by the golden-vector generator
+(``make_golden.py``, which feeds them to the real reference in the build
+container) and by the tests (which feed the very same arrays to the oracle and
+to the HIP engine).  Pure numpy; no reference code involved.
+
+Everything derives from ``np.random.RandomState(seed)`` so fixtures only need
+to store the seed and the reference's outputs, not the inputs.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+f32 = np.float32
+
+
+def _uniform(rng, shape, bound):
+    return rng.uniform(-bound, bound, size=shape).astype(f32)
+
+
+def make_backbone(rng, in_dim, hidden, prefix="backbone.model."):
+    """nn.Linear default init magnitude: W,b ~ U(+-1/sqrt(fan_in))."""
+    p = OrderedDict()
+    d = in_dim
+    for l, h in enumerate(hidden):
+        bound = 1.0 / np.sqrt(d)
+        p[f"{prefix}{2 * l}.weight"] = _uniform(rng, (h, d), bound)
+        p[f"{prefix}{2 * l}.bias"] = _uniform(rng, (h,), bound)
+        d = h
+    return p, d
+
+
+def make_critic(rng, in_dim, hidden):
+    p, d = make_backbone(rng, in_dim, hidden)
+    bound = 1.0 / np.sqrt(d)
+    p["last.weight"] = _uniform(rng, (1, d), bound)
+    p["last.bias"] = _uniform(rng, (1,), bound)
+    return p
+
+
+def make_tanh_actor(rng, obs_dim, act_dim, hidden):
+    """ActorProb(MLP, TanhDiagGaussian(unbounded=True, conditioned_sigma=True))."""
+    p, d = make_backbone(rng, obs_dim, hidden)
+    bound = 1.0 / np.sqrt(d)
+    p["dist_net.mu.weight"] = _uniform(rng, (act_dim, d), bound)
+    p["dist_net.mu.bias"] = _uniform(rng, (act_dim,), bound)
+    p["dist_net.sigma.weight"] = _uniform(rng, (act_dim, d), bound)
+    p["dist_net.sigma.bias"] = _uniform(rng, (act_dim,), bound)
+    return p
+
+
+def make_gauss_actor(rng, obs_dim, act_dim, hidden):
+    """IQL actor: ActorProb(MLP, DiagGaussian(unbounded=False, conditioned_sigma=False))."""
+    p, d = make_backbone(rng, obs_dim, hidden)
+    bound = 1.0 / np.sqrt(d)
+    p["dist_net.sigma_param"] = _uniform(rng, (act_dim, 1), 0.2)
+    p["dist_net.mu.weight"] = _uniform(rng, (act_dim, d), bound)
+    p["dist_net.mu.bias"] = _uniform(rng, (act_dim,), bound)
+    return p
+
+
+def make_det_actor(rng, obs_dim, act_dim, hidden):
+    """TD3BC actor: Actor(MLP, action_dim) -> last Linear + max*tanh."""
+    p, d = make_backbone(rng, obs_dim, hidden)
+    bound = 1.0 / np.sqrt(d)
+    p["last.weight"] = _uniform(rng, (act_dim, d), bound)
+    p["last.bias"] = _uniform(rng, (act_dim,), bound)
+    return p
+
+
+def make_ensemble_critic(rng, in_dim, hidden, K):
+    """EnsembleCritic: model.{0,2,..}.weight (K,in,out), bias (K,1,out)
+    (+ saved_* shadows).  Magnitudes follow run_edac.py:100-103."""
+    p = OrderedDict()
+    dims = [in_dim] + list(hidden) + [1]
+    for l in range(len(dims) - 1):
+        i, o = dims[l], dims[l + 1]
+        std = 1.0 / (2.0 * np.sqrt(i))
+        last = l == len(dims) - 2
+        if last:
+            w = _uniform(rng, (K, i, o), 3e-3)
+            b = _uniform(rng, (K, 1, o), 3e-3)
+        else:
+            w = np.clip(rng.normal(0.0, std, size=(K, i, o)), -2.0, 2.0).astype(f32)
+            b = np.full((K, 1, o), 0.1, dtype=f32)
+        p[f"model.{2 * l}.weight"] = w
+        p[f"model.{2 * l}.bias"] = b
+        p[f"model.{2 * l}.saved_weight"] = w.copy()
+        p[f"model.{2 * l}.saved_bias"] = b.copy()
+    return p
+
+
+def make_batch(rng, B, obs_dim, act_dim, rew_scale=1.0):
+    """D4RL-shaped synthetic minibatch."""
+    return OrderedDict(
+        observations=rng.standard_normal((B, obs_dim)).astype(f32),
+        actions=np.tanh(rng.standard_normal((B, act_dim))).astype(f32),
+        next_observations=rng.standard_normal((B, obs_dim)).astype(f32),
+        terminals=(rng.uniform(size=(B, 1)) < 0.05).astype(f32),
+        rewards=(rng.standard_normal((B, 1)) * rew_scale).astype(f32),
+    )
+
+
+def make_dataset(seed, n, obs_dim, act_dim, term_p=0.01):
+    rng = np.random.RandomState(seed)
+    return OrderedDict(
+        observations=rng.standard_normal((n, obs_dim)).astype(f32),
+        actions=np.tanh(rng.standard_normal((n, act_dim))).astype(f32),
+        next_observations=rng.standard_normal((n, obs_dim)).astype(f32),
+        terminals=(rng.uniform(size=(n,)) < term_p),
+        rewards=rng.standard_normal((n,)).astype(f32),
+    )
+
+
+def make_cql_noise(rng, B, N, A, max_q_backup=False, low=-1.0, high=1.0):
+    """Draw order of CQLPolicy.learn."""
+    n = OrderedDict()
+    n["eps_actor"] = rng.standard_normal((B, A)).astype(f32)
+    n["eps_next"] = rng.standard_normal((B * N if max_q_backup else B, A)).astype(f32)
+    n["u_rand"] = rng.uniform(low, high, size=(B * N, A)).astype(f32)
+    n["eps_pi"] = rng.standard_normal((B * N, A)).astype(f32)
+    n["eps_next_pi"] = rng.standard_normal((B * N, A)).astype(f32)
+    return n
+
+
+def make_sac_noise(rng, B, A, rows_next=None):
+    n = OrderedDict()
+    n["eps_actor"] = rng.standard_normal((B, A)).astype(f32)
+    n["eps_next"] = rng.standard_normal((rows_next or B, A)).astype(f32)
+    return n
+
+
+def make_td3_noise(rng, B, A):
+    return OrderedDict(eps_target=rng.standard_normal((B, A)).astype(f32))
+
+
+# ----------------------------------------------------------------------------
+# digests: compact, order-sensitive summaries of big tensors
+# ----------------------------------------------------------------------------
+
+def digest(arr, n_samples=16):
+    a = np.asarray(arr, dtype=np.float64).ravel()
+    pos = (np.arange(n_samples, dtype=np.int64) * 7919 + 13) % max(a.size, 1)
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[pos]])
+
+
+def digest_net(net):
+    return OrderedDict((k, digest(v)) for k, v in net.items())
+
+
+# ----------------------------------------------------------------------------
+# named configurations used by fixtures
+# ----------------------------------------------------------------------------
+
+CQL_CASES = {
+    # name: dict(obs, act, hidden, B, N, steps, overrides)
+    "cql_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, N=3, steps=5, seed=101, over={}),
+    "cql_tiny_lagrange": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, N=3, steps=5, seed=102,
+                              over=dict(with_lagrange=True)),
+    "cql_tiny_maxq": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, N=3, steps=3, seed=103,
+                          over=dict(max_q_backup=True)),
+    "cql_tiny_stoch_fixed_alpha": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, N=3, steps=3, seed=104,
+                                       over=dict(deterministic_backup=False, auto_alpha=False, alpha=0.2)),
+    "cql_tiny_h3": dict(obs_dim=4, act_dim=2, hidden=[32, 32, 32], B=8, N=4, steps=3, seed=105, over={}),
+    "cql_halfcheetah": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, N=10, steps=20, seed=7, over={}),
+    "cql_halfcheetah_h3": dict(obs_dim=17, act_dim=6, hidden=[256, 256, 256], B=256, N=10, steps=3, seed=8, over={}),
+}
+
+
+def cql_case_inputs(case):
+    """(cfg_overrides, init_state, [batch_k], [noise_k]) for a CQL case."""
+    c = CQL_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    state = OrderedDict()
+    state["actor"] = make_tanh_actor(rng, od, ad, hid)
+    state["critic1"] = make_critic(rng, od + ad, hid)
+    state["critic2"] = make_critic(rng, od + ad, hid)
+    # targets start as perturbed copies so Polyak and the TD target are exercised non-trivially
+    for k in ("critic1", "critic2"):
+        state[k + "_old"] = OrderedDict((n, (v + 0.01 * rng.standard_normal(v.shape)).astype(f32))
+                                        for n, v in state[k].items())
+    state["log_alpha"] = np.array([-0.3], dtype=f32)
+    state["cql_log_alpha"] = np.array([0.2], dtype=f32)
+    mq = bool(c["over"].get("max_q_backup", False))
+    batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
+    noises = [make_cql_noise(rng, c["B"], c["N"], ad, max_q_backup=mq) for _ in range(c["steps"])]
+    return c, state, batches, noises

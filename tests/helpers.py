@@ -1,0 +1,65 @@
+"""Helpers shared by the test modules (oracle drivers, fixture loading, comparisons)."""
+import copy
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(case):
+    return np.load(os.path.join(GOLDEN_DIR, f"{case}.npz"), allow_pickle=False)
+
+
+def clone_state(st):
+    out = OrderedDict()
+    for k, v in st.items():
+        if isinstance(v, dict):
+            out[k] = OrderedDict((n, np.array(a, dtype=np.float32, copy=True)) for n, a in v.items())
+        else:
+            out[k] = np.array(v, dtype=np.float32, copy=True)
+    return out
+
+
+def rel_err(a, b, floor=1e-3):
+    """max |a-b| / max(|b|, floor*scale) with scale = max|b| (robust for near-zero entries)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor * scale)).max())
+
+
+def cql_oracle_setup(case):
+    from oracle import cql as ocql
+    c, st, batches, noises = synth.cql_case_inputs(case)
+    cfg = ocql.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"], num_repeat_actions=c["N"])
+    cfg.update(c["over"])
+    st = clone_state(st)
+    ocql.init_opt(st)
+    return cfg, st, batches, noises
+
+
+def check_state_against_golden(g, tag, nets, atol, rtol=1e-4):
+    """nets: {name: {param: array}}; compares digests (and full arrays when stored)."""
+    worst = 0.0
+    for nm, net in nets.items():
+        for k, v in net.items():
+            key = f"{tag}/{nm}/{k}/digest"
+            if key not in g.files:
+                continue
+            d = synth.digest(v)
+            ref = g[key]
+            # sampled elements: absolute tolerance (Adam's first steps move params by ~lr whatever |g| is)
+            err = np.abs(d[2:] - ref[2:]).max()
+            worst = max(worst, err)
+            assert err <= atol + rtol * np.abs(ref[2:]).max(), (tag, nm, k, err)
+            fkey = f"{tag}/{nm}/{k}/full"
+            if fkey in g.files:
+                ferr = np.abs(np.asarray(v, np.float64) - g[fkey]).max()
+                worst = max(worst, ferr)
+                assert ferr <= atol + rtol * np.abs(g[fkey]).max(), (tag, nm, k, ferr)
+    return worst

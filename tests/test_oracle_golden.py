@@ -1,0 +1,36 @@
+"""CPU: pins the numpy oracle against golden vectors produced by the real
+reference (tests/golden/make_golden.py).  Gate: losses / Q-values within 1e-4
+relative over teacher-forced windows, parameters within a few
+1e-6 absolute (Adam moves them by ~lr per step)."""
+import numpy as np
+import pytest
+
+import synth
+from helpers import load_golden, cql_oracle_setup, rel_err, check_state_against_golden
+
+
+@pytest.mark.parametrize("case", list(synth.CQL_CASES))
+def test_cql_oracle_matches_reference(case):
+    from oracle import cql as ocql
+    g = load_golden(case)
+    cfg, st, batches, noises = cql_oracle_setup(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, aux = ocql.learn(st, cfg, b, n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        ref = g[f"step{k}/losses"]
+        assert rel_err(got, ref, floor=1e-2) < 1e-4, (case, k, got, ref)
+        if k == 0:
+            assert rel_err(aux["q1a"], g["step0/c1_qa"]) < 1e-4
+            assert rel_err(aux["q2a"], g["step0/c2_qa"]) < 1e-4
+            assert rel_err(aux["q1"], g["step0/c1_q"]) < 1e-4
+            assert rel_err(aux["q2"], g["step0/c2_q"]) < 1e-4
+            if "step0/target_q" in g.files:
+                assert rel_err(aux["target_q"], g["step0/target_q"]) < 1e-4
+        if k in (0, len(batches) - 1):
+            nets = {nm: st[nm] for nm in ("actor", "critic1", "critic2", "critic1_old", "critic2_old")}
+            check_state_against_golden(g, f"state{k}", nets, atol=2e-6 * (k + 1))
+            if cfg["auto_alpha"]:
+                assert abs(float(st["log_alpha"][0]) - float(g[f"state{k}/log_alpha"][0])) < 1e-6
+            assert abs(float(st["cql_log_alpha"][0]) - float(g[f"state{k}/cql_log_alpha"][0])) < 1e-6
