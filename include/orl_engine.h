@@ -1,0 +1,190 @@
+/*
+ * orl_engine.h — C ABI of the MI355X-native offline-RL update engine.
+ *
+ * This is the drop-in boundary for the policy.learn() hot path of the
+ * reference (zhaoyizhou1123/OfflineRL-Kit).  The reference has no FFI layer:
+ * its boundary is the duck-typed Python interface
+ *     BasePolicy.learn(batch) -> Dict[str,float]   (offlinerlkit/policy/base_policy.py:8-26)
+ *     ReplayBuffer.sample(batch_size) -> Dict      (offlinerlkit/buffer/buffer.py:96-106)
+ *     MFPolicyTrainer.train()                      (offlinerlkit/policy_trainer/mf_policy_trainer.py:41-90)
+ * Each entry point below names the reference code it replaces.  Signatures
+ * are plain C: pointers, sizes, no torch types.  The Python mirror
+ * (offlinerl-kit_amd/offlinerlkit) binds them with ctypes; INTEGRATION.md shows
+ * the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returning int returns 0 on success, non-zero on error;
+ *     the message is available from orl_last_error() (thread-local).
+ *   - one engine = one device + one HIP stream; an engine is not thread-safe.
+ *   - an engine carries `n_runs` independent runs (seeds) that are updated
+ *     together by every kernel launch (run-batched, like an ensemble).  All
+ *     host-side arrays have a leading run dimension [n_runs][...].
+ *   - all floating point is fp32.  `precision` selects the MFMA scheme used by
+ *     the GEMMs only: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
+ *     1 = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate).
+ */
+#ifndef ORL_ENGINE_H
+#define ORL_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORL_ALGO_CQL 0   /* policy/model_free/cql.py:87-207   */
+#define ORL_ALGO_IQL 1   /* policy/model_free/iql.py:86-139   */
+#define ORL_ALGO_TD3BC 2 /* policy/model_free/td3bc.py:83-124 */
+#define ORL_ALGO_EDAC 3  /* policy/model_free/edac.py:88-166  */
+
+#define ORL_MAX_HIDDEN 4
+#define ORL_MAX_METRICS 8
+#define ORL_MAX_NOISE 6
+
+/* network ids (per algorithm; state_dict prefixes of SURVEY.md Appendix B) */
+#define ORL_NET_ACTOR 0
+#define ORL_NET_CRITIC1 1     /* IQL: critic_q1 ; EDAC: critics (ensemble) */
+#define ORL_NET_CRITIC2 2     /* IQL: critic_q2 */
+#define ORL_NET_CRITIC1_OLD 3 /* EDAC: critics_old */
+#define ORL_NET_CRITIC2_OLD 4
+#define ORL_NET_CRITIC_V 5    /* IQL only  */
+#define ORL_NET_ACTOR_OLD 6   /* TD3BC only */
+#define ORL_NUM_NETS 7
+
+/* per-run scalars (not nn.Parameters in the reference: run_cql.py:102, cql.py:57) */
+#define ORL_SCALAR_LOG_ALPHA 0
+#define ORL_SCALAR_CQL_LOG_ALPHA 1
+#define ORL_SCALAR_ALPHA 2 /* read-only: the alpha the next learn() will use */
+
+/* optimizer ids for orl_set_lr (run_iql.py:133 mutates actor_optim's lr per epoch) */
+#define ORL_OPT_ACTOR 0
+#define ORL_OPT_CRITIC 1
+#define ORL_OPT_ALPHA 2
+#define ORL_OPT_CQL_ALPHA 3
+#define ORL_OPT_CRITIC_V 4
+
+typedef struct orl_config {
+  int32_t algo;
+  int32_t obs_dim, act_dim;
+  int32_t n_hidden;
+  int32_t hidden[ORL_MAX_HIDDEN];
+  int32_t batch_size;
+  int32_t n_runs;    /* independent runs carried by this engine (>=1) */
+  int32_t device;    /* HIP device ordinal */
+  int32_t precision; /* 0 fp32 MFMA, 1 split-bf16 */
+  uint64_t seed;     /* device Philox seed for orl_learn_n */
+  float gamma, tau;
+  float actor_lr, critic_lr, alpha_lr;
+  float adam_beta1, adam_beta2, adam_eps;
+  /* SAC family (sac.py:42-48) */
+  int32_t auto_alpha;
+  float alpha;
+  float target_entropy;
+  /* CQL (cql.py:16-60) */
+  float cql_weight, temperature;
+  int32_t max_q_backup, deterministic_backup, with_lagrange;
+  float lagrange_threshold, cql_alpha_lr;
+  int32_t num_repeat_actions;
+  float act_low, act_high;
+  /* IQL (iql.py:16-50) */
+  float expectile, iql_temperature, critic_v_lr;
+  /* TD3+BC (td3bc.py:17-53) */
+  float policy_noise, noise_clip, td3bc_alpha, max_action;
+  int32_t update_actor_freq;
+  /* EDAC (edac.py:15-52) */
+  int32_t num_critics;
+  float eta;
+  /* optional caller-owned parameter arena (device pointer, orl_arena_floats()
+   * floats) so that framework tensors can alias engine parameters; NULL = the
+   * engine allocates with hipMalloc. */
+  float* external_arena;
+} orl_config;
+
+/* Replay minibatch: the dict ReplayBuffer.sample returns (buffer.py:96-106).
+ * Arrays are [n_runs][batch][dim] row-major; rewards/terminals [n_runs][batch]. */
+typedef struct orl_batch {
+  const float* observations;
+  const float* actions;
+  const float* next_observations;
+  const float* rewards;
+  const float* terminals;
+  int32_t on_device; /* 0: host pointers (copied in), 1: device pointers */
+} orl_batch;
+
+/* Explicit noise for a teacher-forced step, in the reference's draw order.
+ * CQL: [0] eps_actor (B,A) N(0,1); [1] eps_next (B,A) or (B*N,A) with
+ * max_q_backup; [2] u_rand (B*N,A) U[low,high); [3] eps_pi (B*N,A); [4] eps_next_pi (B*N,A).
+ * EDAC: [0] eps_actor, [1] eps_next.  TD3BC: [0] eps_target (B,A).  IQL: none.
+ * Each array has a leading n_runs dimension. */
+typedef struct orl_noise {
+  const float* slot[ORL_MAX_NOISE];
+  int32_t on_device;
+} orl_noise;
+
+typedef struct orl_engine orl_engine;
+
+/* -- lifecycle --------------------------------------------------------------- */
+const char* orl_last_error(void);
+const char* orl_version(void);
+void orl_config_default(orl_config* cfg, int32_t algo); /* script defaults: run_{cql,iql,td3bc,edac}.py get_args() */
+int64_t orl_arena_floats(const orl_config* cfg);        /* size of the parameter arena for external_arena */
+int orl_engine_create(const orl_config* cfg, orl_engine** out); /* replaces <Algo>Policy.__init__ + deepcopy of targets (sac.py:29-33) */
+void orl_engine_destroy(orl_engine* e);
+int orl_engine_sync(orl_engine* e);                     /* hipStreamSynchronize on the engine stream */
+
+/* -- parameters (nn.Module.state_dict() view) -------------- */
+int orl_net_present(orl_engine* e, int net);
+int64_t orl_net_floats(orl_engine* e, int net);
+int orl_net_num_tensors(orl_engine* e, int net);
+/* name: reference state_dict key relative to the net prefix (e.g. "backbone.model.0.weight") */
+int orl_net_tensor(orl_engine* e, int net, int idx, char* name, int name_cap, int64_t* offset_floats,
+                   int32_t* ndim, int64_t shape[4]);
+float* orl_net_ptr(orl_engine* e, int run, int net);    /* device pointer to the net's flat fp32 parameters */
+int orl_net_set(orl_engine* e, int run, int net, const float* host, int64_t n_floats); /* load_state_dict */
+int orl_net_get(orl_engine* e, int run, int net, float* host, int64_t n_floats);       /* state_dict */
+int orl_scalar_set(orl_engine* e, int run, int which, float v);
+int orl_scalar_get(orl_engine* e, int run, int which, float* v);
+int orl_set_lr(orl_engine* e, int opt, float lr);       /* optim.param_groups[0]["lr"] = lr */
+int orl_reset_optimizers(orl_engine* e);                /* fresh torch.optim.Adam state (step=0, m=v=0) */
+
+/* -- replay buffer (buffer/buffer.py) ------------------------------------------ */
+/* load_dataset (:72-86): host arrays -> HBM-resident SoA; obs/next_obs [n][obs_dim], act [n][act_dim], rew/term [n] */
+int orl_buffer_load(orl_engine* e, const float* obs, const float* act, const float* next_obs, const float* rew,
+                    const float* term, int64_t n);
+/* normalize_obs (:88-94): in place on device; writes mean/std (obs_dim each) to host */
+int orl_buffer_normalize_obs(orl_engine* e, float eps, float* mean_out, float* std_out);
+/* sample (:96-106): gather rows idx[n_runs][batch] (host int64; NULL = device Philox indices) into the engine's
+ * batch slots; out (optional) receives device pointers to the gathered, padded-free copies. */
+int orl_buffer_sample(orl_engine* e, const int64_t* idx, orl_batch* out);
+int64_t orl_buffer_size(orl_engine* e);
+
+/* -- the hot path ---------------------------------------------------------------- */
+/* policy.learn(batch) with explicit noise: one gradient step for every run.
+ * metrics: host [n_runs][ORL_MAX_METRICS] in the reference's result-dict order
+ * (orl_metric_name); synchronous, like the reference's .item() calls. */
+int orl_step(orl_engine* e, const orl_batch* batch, const orl_noise* noise, float* metrics);
+/* MFPolicyTrainer inner loop (mf_policy_trainer.py:52-60): n x {sample -> learn -> logkv_mean},
+ * sampling and noise on device; metrics_mean: host [n_runs][ORL_MAX_METRICS] epoch means;
+ * elapsed_ms (optional): HIP-event time of the n steps on the engine stream. */
+int orl_learn_n(orl_engine* e, int n_steps, float* metrics_mean, float* elapsed_ms);
+int orl_num_metrics(orl_engine* e);
+const char* orl_metric_name(orl_engine* e, int idx);
+int64_t orl_step_count(orl_engine* e);
+
+/* -- test / profiling taps --------------------------------------------------------- */
+/* copies an intermediate of the LAST step to host: returns number of floats written or <0.
+ * names: "q1","q2","target_q","q1a","q2a","logp_a", ... (algorithm specific) */
+int64_t orl_debug_read(orl_engine* e, int run, const char* name, float* host, int64_t cap);
+/* runs one generic GEMM tile configuration on host data (kernel unit tests): see csrc/gemm.h */
+int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* B, const float* v0,
+                   const float* v1, float* C, int ksplit, int precision);
+/* average duration (ms) of the kernel with the largest accumulated time during the last orl_learn_n
+ * when profiling was enabled with orl_profile_enable(e,1); name copied to `name`. */
+int orl_profile_enable(orl_engine* e, int on);
+int orl_profile_query(orl_engine* e, int idx, char* name, int name_cap, double* total_ms, int64_t* launches,
+                      double* flops_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORL_ENGINE_H */

@@ -1,0 +1,435 @@
+// kernels.h — non-GEMM device kernels of the update engine: replay gather + device RNG, tanh-Gaussian
+// sampling and its backward, loss / gradient-seed kernels, fused Adam + split-K slab reduce + Polyak.
+// Every kernel is batched over runs (and nets where it applies) through blockIdx.y / blockIdx.z.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace orl {
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (device sampling of indices / noise in orl_learn_n)
+// ------------------------------------------------------------------------------------------------
+struct Philox {
+  uint32_t k0, k1;
+  __device__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+  __device__ void operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+    uint32_t a = k0, b = k1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ a, n1 = (uint32_t)p1;
+      const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ b, n3 = (uint32_t)p0;
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      a += 0x9E3779B9u; b += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+  }
+};
+__device__ inline float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+__device__ inline void box_muller(uint32_t x, uint32_t y, float& n0, float& n1) {
+  const float r = sqrtf(-2.0f * logf(u01(x)));
+  const float t = 6.28318530717958647692f * u01(y);
+  n0 = r * cosf(t); n1 = r * sinf(t);
+}
+
+// per-run scalars kept on the device so captured graphs replay without host patching
+struct RunScalars {
+  float log_alpha, la_m, la_v;          // SAC temperature + its Adam moments (run_cql.py:102-103)
+  float cql_log_alpha, cla_m, cla_v;    // CQL Lagrange multiplier (cql.py:57-58)
+  float alpha;                          // alpha used by the NEXT actor loss (sac.py:46 / cql.py:106)
+  float alpha_bwd;                      // alpha the current actor backward must use (pre-update value)
+  float cons_scale;                     // cql_alpha seen by the critic gradients (cql.py:170-178)
+  float last_actor_loss;                // TD3BC _last_actor_loss (td3.py:59)
+  float pad[6];
+};
+
+struct Hyper {                          // mutable hyper-parameters (orl_set_lr)
+  float lr[8];
+};
+
+// ------------------------------------------------------------------------------------------------
+// device step counter: Adam's t and the Philox offsets derive from it
+// ------------------------------------------------------------------------------------------------
+__global__ void k_tick(unsigned long long* gstep) { *gstep += 1ull; }
+
+// ------------------------------------------------------------------------------------------------
+// replay gather (buffer.py:96-106).  SoA in HBM, rows padded to 16 B so one row = whole float4 loads.
+// idx == nullptr -> Philox indices (np.random.randint(0, size, B) restated on device).
+// grid (ceil(B/64), R), block 256: 4 threads per row cooperate.
+// ------------------------------------------------------------------------------------------------
+struct GatherP {
+  const float *obs, *nobs, *act, *rew, *term;  // dataset [n][OP], [n][OP], [n][AP], [n], [n]
+  long n;
+  int OP, AP, od, ad, B;
+  const long long* idx;                         // [R][B] or null
+  float *b_obs, *b_nobs, *b_act, *b_rew, *b_term;  // batch slots [R][B][OP] ...
+  unsigned long long seed;
+  const unsigned long long* gstep;
+};
+__global__ void k_gather(GatherP p) {
+  const int r = blockIdx.y;
+  const int row = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const int sub = threadIdx.x & 3;
+  if (row >= p.B) return;
+  long j;
+  if (p.idx) j = p.idx[(long)r * p.B + row];
+  else {
+    Philox ph(p.seed);
+    uint32_t o[4];
+    ph((uint32_t)row, (uint32_t)r, (uint32_t)(*p.gstep), 0x1D5u ^ (uint32_t)((*p.gstep) >> 32), o);
+    j = (long)(((unsigned long long)o[0] * (unsigned long long)p.n) >> 32);
+  }
+  const long dst = (long)r * p.B + row;
+  for (int c = sub * 4; c < p.OP; c += 16) {
+    *(float4*)&p.b_obs[dst * p.OP + c] = *(const float4*)&p.obs[j * p.OP + c];
+    *(float4*)&p.b_nobs[dst * p.OP + c] = *(const float4*)&p.nobs[j * p.OP + c];
+  }
+  for (int c = sub * 4; c < p.AP; c += 16) *(float4*)&p.b_act[dst * p.AP + c] = *(const float4*)&p.act[j * p.AP + c];
+  if (sub == 0) { p.b_rew[dst] = p.rew[j]; p.b_term[dst] = p.term[j]; }
+}
+
+// device noise: fills `n` floats per run with N(0,1) (kind 0) or U[lo,hi) (kind 1)
+__global__ void k_noise(float* out, long n_per_run, int kind, float lo, float hi, unsigned long long seed,
+                        const unsigned long long* gstep, uint32_t stream_id) {
+  const int r = blockIdx.y;
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n_per_run) return;
+  Philox ph(seed);
+  uint32_t o[4];
+  ph((uint32_t)(i4 >> 2), (uint32_t)r | (stream_id << 16), (uint32_t)(*gstep), 0xA5u ^ (uint32_t)((*gstep) >> 32), o);
+  float v[4];
+  if (kind == 0) { box_muller(o[0], o[1], v[0], v[1]); box_muller(o[2], o[3], v[2], v[3]); }
+  else { for (int k = 0; k < 4; ++k) v[k] = lo + (hi - lo) * u01(o[k]); }
+  float* dst = out + (long)r * n_per_run;
+  for (int k = 0; k < 4; ++k) if (i4 + k < n_per_run) dst[i4 + k] = v[k];
+}
+
+// ------------------------------------------------------------------------------------------------
+// critic-input assembly: X[row] = (obs_src[row / rep], act_src[row]) with pitch XP (zero padded)
+// grid (ceil(rows/256), R)
+// ------------------------------------------------------------------------------------------------
+struct AssembleP {
+  const float* obs; long obs_rs; int OP, od;    // [R][B][OP]
+  const float* act; long act_rs; int apitch, ad; // [R][rows][apitch] or null (leave action cols untouched)
+  float* X; long x_rs; int XP;                   // [R][rows_total][XP]; writes rows [row0, row0+rows)
+  int row0, rows, rep;
+};
+__global__ void k_assemble(AssembleP p) {
+  const int r = blockIdx.y;
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= p.rows) return;
+  const float* o = p.obs + (long)r * p.obs_rs + (long)(row / p.rep) * p.OP;
+  float* x = p.X + (long)r * p.x_rs + (long)(p.row0 + row) * p.XP;
+  for (int c = 0; c < p.od; ++c) x[c] = o[c];
+  if (p.act) {
+    const float* a = p.act + (long)r * p.act_rs + (long)row * p.apitch;
+    for (int c = 0; c < p.ad; ++c) x[p.od + c] = a[c];
+  }
+  for (int c = p.od + p.ad; c < p.XP; ++c) x[c] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tanh-Gaussian sampling (dist_module.py:117-127, :17-42): head = [mu | log_sigma_raw] per base row.
+// One thread per output row; up to 3 jobs per launch (blockIdx.y), runs in blockIdx.z.
+// ------------------------------------------------------------------------------------------------
+#define ORL_LOG_SQRT_2PI 0.91893853320467274178f
+struct SampleJob {
+  int head_row0;     // first base row inside head
+  int rows;          // output rows
+  int rep;           // output row j uses base row head_row0 + j / rep
+  const float* eps;  long eps_rs;   // [R][rows][A] or null (deterministic)
+  float* dst;        long dst_rs; int dst_pitch, dst_col, dst_row0;  // actions -> dst[(dst_row0+j)*pitch + col + a]
+  float* logp;       long logp_rs;  // [R][rows] or null
+};
+struct SampleP {
+  const float* head; long head_rs; int A;   // [R][rows_head][2A]
+  SampleJob job[3];
+};
+__global__ void k_tanh_sample(SampleP p) {
+  const SampleJob& jb = p.job[blockIdx.y];
+  const int r = blockIdx.z;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= jb.rows) return;
+  const int A = p.A;
+  const float* h = p.head + (long)r * p.head_rs + (long)(jb.head_row0 + j / jb.rep) * (2 * A);
+  const float* e = jb.eps ? jb.eps + (long)r * jb.eps_rs + (long)j * A : nullptr;
+  float* d = jb.dst + (long)r * jb.dst_rs + (long)(jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col;
+  float lp = 0.f, lj = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float mu = h[a];
+    const float ls = fminf(fmaxf(h[A + a], -5.0f), 2.0f);
+    const float sg = expf(ls);
+    const float u = e ? mu + sg * e[a] : mu;
+    const float act = tanhf(u);
+    d[a] = act;
+    const float dm = u - mu;
+    lp += -(dm * dm) / (2.0f * (sg * sg)) - ls - ORL_LOG_SQRT_2PI;
+    lj += logf((1.0f - act * act) + 1e-6f);
+  }
+  if (jb.logp) jb.logp[(long)r * jb.logp_rs + j] = lp - lj;
+}
+
+// block-wide sum over 256 threads (4 waves of 64)
+__device__ inline float block_sum256(float v, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const float t = sh[0] + sh[1] + sh[2] + sh[3];
+  return t;
+}
+
+// scalar Adam (log_alpha, cql_log_alpha): torch.optim.Adam single-tensor semantics
+__device__ inline void adam_scalar(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps,
+                                   unsigned long long t) {
+  m = m + (g - m) * (1.0f - b1);
+  v = v * b2 + (1.0f - b2) * g * g;
+  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
+  const float step = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
+  p -= step * (m / (sqrtf(v) / bc2s + eps));
+}
+
+// ------------------------------------------------------------------------------------------------
+// SAC-style actor loss + temperature step (cql.py:92-106, edac.py:96-110)
+//   L = mean(alpha*logp - min_c q_c) ; dq_c = -1/B routed to the min ; alpha Adam step.
+// grid (R), block 256, loops over B.  K critics (2 for CQL).
+// ------------------------------------------------------------------------------------------------
+struct ActorLossP {
+  const float* qa; long qa_rs, qa_cs;      // [R][K][B]
+  float* dqa;                              // same layout
+  const float* logp; long logp_rs;         // [R][B]
+  int B, K;
+  RunScalars* sc; const Hyper* hy;
+  int auto_alpha; float fixed_alpha, target_entropy; int clamp_alpha01;
+  float b1, b2, eps;
+  const unsigned long long* gstep;
+  float* metrics_last; float* metrics_sum; int nm;  // [R][nm]
+  int m_actor, m_alpha_loss, m_alpha;              // metric slots (-1 = none)
+};
+__global__ void k_actor_loss(ActorLossP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  RunScalars& sc = p.sc[r];
+  const float alpha = p.auto_alpha ? sc.alpha : p.fixed_alpha;
+  float s_loss = 0.f, s_lp = 0.f;
+  const float gq = -1.0f / (float)p.B;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    const float* q = p.qa + (long)r * p.qa_rs + b;
+    float qmin = q[0];
+    for (int c = 1; c < p.K; ++c) qmin = fminf(qmin, q[(long)c * p.qa_cs]);
+    int nmin = 0;
+    for (int c = 0; c < p.K; ++c) nmin += (q[(long)c * p.qa_cs] == qmin);
+    float* dq = p.dqa + (long)r * p.qa_rs + b;
+    for (int c = 0; c < p.K; ++c) dq[(long)c * p.qa_cs] = (q[(long)c * p.qa_cs] == qmin) ? gq / (float)nmin : 0.f;
+    const float lp = p.logp[(long)r * p.logp_rs + b];
+    s_loss += alpha * lp - qmin;
+    s_lp += lp;
+  }
+  s_loss = block_sum256(s_loss, sh);
+  s_lp = block_sum256(s_lp, sh);
+  if (threadIdx.x == 0) {
+    float* ml = p.metrics_last + (long)r * p.nm;
+    float* ms = p.metrics_sum + (long)r * p.nm;
+    const float loss = s_loss / (float)p.B;
+    ml[p.m_actor] = loss; ms[p.m_actor] += loss;
+    sc.alpha_bwd = alpha;
+    if (p.auto_alpha) {
+      // alpha_loss = -(log_alpha * (logp + target_entropy)).mean()
+      const float mean_t = s_lp / (float)p.B + p.target_entropy;
+      const float aloss = -(sc.log_alpha * mean_t);
+      adam_scalar(sc.log_alpha, sc.la_m, sc.la_v, -mean_t, p.hy->lr[2], p.b1, p.b2, p.eps, *p.gstep + 1ull);
+      float na = expf(sc.log_alpha);
+      if (p.clamp_alpha01) na = fminf(fmaxf(na, 0.f), 1.f);
+      sc.alpha = na;
+      ml[p.m_alpha_loss] = aloss; ms[p.m_alpha_loss] += aloss;
+      ml[p.m_alpha] = na; ms[p.m_alpha] += na;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of the tanh-Gaussian head for the actor loss (rsample path; oracle/nn.py tanh_gauss_bwd)
+//   da = sum_c dx_c[:, action cols] ; dlogp = alpha/B
+// grid (ceil(B/256), R)
+// ------------------------------------------------------------------------------------------------
+struct HeadBwdP {
+  const float* dxa; long dxa_rs, dxa_cs; int dxa_pitch; int K;  // [R][K][B][pitch] action-column grads
+  const float* head; long head_rs;                                // [R][B][2A]
+  const float* eps; long eps_rs;                                  // [R][B][A]
+  const float* xa; long xa_rs; int XP, od;                        // actions live in Xa[:, od:]
+  float* dhead; long dhead_rs;                                    // [R][B][2A]
+  const RunScalars* sc; int auto_alpha; float fixed_alpha;
+  int B, A;
+};
+__global__ void k_head_bwd(HeadBwdP p) {
+  const int r = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const int A = p.A;
+  const float alpha = p.auto_alpha ? p.sc[r].alpha_bwd : p.fixed_alpha;
+  const float dlogp = alpha / (float)p.B;
+  const float* h = p.head + (long)r * p.head_rs + (long)b * 2 * A;
+  const float* e = p.eps + (long)r * p.eps_rs + (long)b * A;
+  const float* x = p.xa + (long)r * p.xa_rs + (long)b * p.XP + p.od;
+  float* dh = p.dhead + (long)r * p.dhead_rs + (long)b * 2 * A;
+  for (int a = 0; a < A; ++a) {
+    float da = 0.f;
+    for (int c = 0; c < p.K; ++c) da += p.dxa[(long)r * p.dxa_rs + (long)c * p.dxa_cs + (long)b * p.dxa_pitch + a];
+    const float lsr = h[A + a];
+    const float sg = expf(fminf(fmaxf(lsr, -5.0f), 2.0f));
+    const float act = x[a];
+    const float om = 1.0f - act * act;
+    const float t = 2.0f * act * om / (om + 1e-6f);
+    const float du = da * om + dlogp * t;
+    const float dls = du * sg * e[a] - dlogp;
+    dh[a] = du;
+    dh[A + a] = (lsr >= -5.0f && lsr <= 2.0f) ? dls : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CQL critic loss + gradient seeds (cql.py:108-190, oracle/cql.py).  One block per run.
+//   rows of q[c]: [0,B) data, [B,B+BN) pi, [B+BN,B+2BN) next-pi, [B+2BN,B+3BN) random
+// ------------------------------------------------------------------------------------------------
+struct CqlLossP {
+  const float* q; long q_rs, q_cs;         // [R][2][Mc]
+  float* dq;                               // [R][2][Mc]
+  const float* qt; long qt_rs, qt_cs;      // target critics [R][2][Bt]  (Bt = B or B*N with max_q_backup)
+  const float* rew; const float* term; long bt_rs;  // [R][B]
+  const float* logp_next; long lpn_rs;     // [R][B]   (stochastic backup)
+  const float* logp_pi; const float* logp_npi; long lpp_rs;   // [R][BN]
+  float* target_q; long tq_rs;             // [R][B] (tap)
+  int B, N, A;
+  float gamma, w, T, thr;
+  int max_q_backup, det_backup, with_lagrange, auto_alpha; float fixed_alpha;
+  RunScalars* sc; const Hyper* hy; float b1, b2, eps;
+  const unsigned long long* gstep;
+  float* metrics_last; float* metrics_sum; int nm;
+  int m_c1, m_c2, m_cqla_loss, m_cqla;
+};
+__global__ void k_cql_loss(CqlLossP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  RunScalars& sc = p.sc[r];
+  const int B = p.B, BN = p.B * p.N;
+  const float alpha = p.auto_alpha ? sc.alpha : p.fixed_alpha;
+  float cs = 1.0f, e_cla = 0.f;
+  if (p.with_lagrange) { e_cla = expf(sc.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
+  const float log_rand = logf(powf(0.5f, (float)p.A));
+  float* tq = p.target_q + (long)r * p.tq_rs;
+  // target_q
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* t0 = p.qt + (long)r * p.qt_rs;
+    const float* t1 = t0 + p.qt_cs;
+    float nq;
+    if (p.max_q_backup) {
+      float m0 = -INFINITY, m1 = -INFINITY;
+      for (int n = 0; n < p.N; ++n) { m0 = fmaxf(m0, t0[b * p.N + n]); m1 = fmaxf(m1, t1[b * p.N + n]); }
+      nq = fminf(m0, m1);
+    } else {
+      nq = fminf(t0[b], t1[b]);
+      if (!p.det_backup) nq -= alpha * p.logp_next[(long)r * p.lpn_rs + b];
+    }
+    tq[b] = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
+  }
+  __syncthreads();
+  float raw[2];
+  for (int c = 0; c < 2; ++c) {
+    const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
+    float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
+    float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const float d = q[b] - tq[b];
+      s_td += d * d; s_q += q[b];
+      dq[b] = 2.0f * d / (float)B - cs * p.w / (float)B;
+    }
+    const float* lpp = p.logp_pi + (long)r * p.lpp_rs;
+    const float* lpn = p.logp_npi + (long)r * p.lpp_rs;
+    const float gs = cs * p.w / (float)BN;
+    for (int j = threadIdx.x; j < BN; j += 256) {
+      const float v0 = (q[B + j] - lpp[j]) / p.T, v1 = (q[B + BN + j] - lpn[j]) / p.T, v2 = (q[B + 2 * BN + j] - log_rand) / p.T;
+      const float mx = fmaxf(v0, fmaxf(v1, v2));
+      const float e0 = expf(v0 - mx), e1 = expf(v1 - mx), e2 = expf(v2 - mx);
+      const float se = e0 + e1 + e2;
+      s_lse += logf(se) + mx;
+      dq[B + j] = gs * (e0 / se); dq[B + BN + j] = gs * (e1 / se); dq[B + 2 * BN + j] = gs * (e2 / se);
+    }
+    s_td = block_sum256(s_td, sh);
+    s_q = block_sum256(s_q, sh);
+    s_lse = block_sum256(s_lse, sh);
+    float cons = (s_lse / (float)BN) * p.w * p.T - (s_q / (float)B) * p.w;
+    raw[c] = cons - p.thr;
+    if (p.with_lagrange) cons = cs * raw[c];
+    if (threadIdx.x == 0) {
+      const float loss = s_td / (float)B + cons;
+      const int slot = c == 0 ? p.m_c1 : p.m_c2;
+      p.metrics_last[(long)r * p.nm + slot] = loss; p.metrics_sum[(long)r * p.nm + slot] += loss;
+    }
+  }
+  if (p.with_lagrange && threadIdx.x == 0) {
+    const float l = -(cs * raw[0] + cs * raw[1]) * 0.5f;
+    const float gate = (e_cla >= 0.f && e_cla <= 1e6f) ? 1.f : 0.f;
+    const float g = -(raw[0] + raw[1]) * 0.5f * e_cla * gate;
+    adam_scalar(sc.cql_log_alpha, sc.cla_m, sc.cla_v, g, p.hy->lr[3], p.b1, p.b2, p.eps, *p.gstep + 1ull);
+    p.metrics_last[(long)r * p.nm + p.m_cqla_loss] = l; p.metrics_sum[(long)r * p.nm + p.m_cqla_loss] += l;
+    p.metrics_last[(long)r * p.nm + p.m_cqla] = cs; p.metrics_sum[(long)r * p.nm + p.m_cqla] += cs;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused Adam (torch.optim.Adam defaults) + split-K slab reduce + optional Polyak
+// (sac.py:60-64).  grid (ceil(P/256), nz1, nz0): z1 = net, z0 = run.
+// ------------------------------------------------------------------------------------------------
+struct AdamP {
+  float* params; long p_s0, p_s1;     // [z0][z1][P]
+  float* m; float* v;                 // same strides as params
+  const float* g; long g_s0, g_s1, g_ks;
+  int nseg; long seg_end[8]; int seg_nslab[8];   // per-tensor-group split-K slab counts
+  float* target; long t_s0, t_s1;     // Polyak target or null
+  long P;
+  int lr_slot; const Hyper* hy;
+  float b1, b2, eps, tau;
+  const unsigned long long* gstep; unsigned long long t_div;  // t = gstep / t_div + 1
+};
+__global__ void k_adam(AdamP p) {
+  __shared__ float s_step, s_bc2s;
+  if (threadIdx.x == 0) {
+    const unsigned long long t = *p.gstep / p.t_div + 1ull;
+    const double bc1 = 1.0 - pow((double)p.b1, (double)t), bc2 = 1.0 - pow((double)p.b2, (double)t);
+    s_step = (float)((double)p.hy->lr[p.lr_slot] / bc1);
+    s_bc2s = (float)sqrt(bc2);
+  }
+  __syncthreads();
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.P) return;
+  const int z1 = blockIdx.y, z0 = blockIdx.z;
+  const float* g = p.g + z0 * p.g_s0 + z1 * p.g_s1 + i;
+  int nslab = p.seg_nslab[0];
+  for (int k = 1; k < p.nseg; ++k) if (i >= p.seg_end[k - 1]) nslab = p.seg_nslab[k];
+  float gs = 0.f;
+  for (int s = 0; s < nslab; ++s) gs += g[(long)s * p.g_ks];
+  const long o = z0 * p.p_s0 + z1 * p.p_s1 + i;
+  float m = p.m[o], v = p.v[o], w = p.params[o];
+  m = m + (gs - m) * (1.0f - p.b1);
+  v = v * p.b2 + (1.0f - p.b2) * gs * gs;
+  w -= s_step * (m / (sqrtf(v) / s_bc2s + p.eps));
+  p.m[o] = m; p.v[o] = v; p.params[o] = w;
+  if (p.target) {
+    float* t = p.target + z0 * p.t_s0 + z1 * p.t_s1 + i;
+    *t = *t * (1.0f - p.tau) + w * p.tau;
+  }
+}
+
+// Polyak only (targets whose nets were updated earlier in the step)
+__global__ void k_polyak(float* target, long t_s0, long t_s1, const float* src, long s_s0, long s_s1, long P, float tau) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  float* t = target + blockIdx.z * t_s0 + blockIdx.y * t_s1 + i;
+  const float w = src[blockIdx.z * s_s0 + blockIdx.y * s_s1 + i];
+  *t = *t * (1.0f - tau) + w * tau;
+}
+
+}  // namespace orl

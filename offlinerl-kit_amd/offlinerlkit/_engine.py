@@ -1,0 +1,328 @@
+"""ctypes binding of the C-ABI update engine (include/orl_engine.h -> liborlengine.so).
+
+This is the only place Python touches the native library.  There is NO CPU
+fallback: if the shared object is missing or no MI355X is visible, creating an
+engine raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "liborlengine.so")
+
+ALGO_CQL, ALGO_IQL, ALGO_TD3BC, ALGO_EDAC = 0, 1, 2, 3
+ALGO_ID = {"cql": ALGO_CQL, "iql": ALGO_IQL, "td3bc": ALGO_TD3BC, "edac": ALGO_EDAC}
+MAX_HIDDEN, MAX_METRICS, MAX_NOISE = 4, 8, 6
+NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC1_OLD, NET_CRITIC2_OLD, NET_CRITIC_V, NET_ACTOR_OLD = range(7)
+NUM_NETS = 7
+SCALAR_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA, SCALAR_ALPHA = 0, 1, 2
+OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V = range(5)
+
+# symbols include/orl_engine.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "orl_last_error", "orl_version", "orl_config_default", "orl_arena_floats", "orl_engine_create",
+    "orl_engine_destroy", "orl_engine_sync", "orl_net_present", "orl_net_floats", "orl_net_num_tensors",
+    "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
+    "orl_set_lr", "orl_reset_optimizers", "orl_buffer_load", "orl_buffer_normalize_obs", "orl_buffer_sample",
+    "orl_buffer_size", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
+    "orl_debug_read", "orl_debug_gemm", "orl_profile_enable", "orl_profile_query",
+]
+
+
+class OrlConfig(C.Structure):
+    _fields_ = [
+        ("algo", C.c_int32), ("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32),
+        ("hidden", C.c_int32 * MAX_HIDDEN), ("batch_size", C.c_int32), ("n_runs", C.c_int32),
+        ("device", C.c_int32), ("precision", C.c_int32), ("seed", C.c_uint64),
+        ("gamma", C.c_float), ("tau", C.c_float),
+        ("actor_lr", C.c_float), ("critic_lr", C.c_float), ("alpha_lr", C.c_float),
+        ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float),
+        ("auto_alpha", C.c_int32), ("alpha", C.c_float), ("target_entropy", C.c_float),
+        ("cql_weight", C.c_float), ("temperature", C.c_float),
+        ("max_q_backup", C.c_int32), ("deterministic_backup", C.c_int32), ("with_lagrange", C.c_int32),
+        ("lagrange_threshold", C.c_float), ("cql_alpha_lr", C.c_float), ("num_repeat_actions", C.c_int32),
+        ("act_low", C.c_float), ("act_high", C.c_float),
+        ("expectile", C.c_float), ("iql_temperature", C.c_float), ("critic_v_lr", C.c_float),
+        ("policy_noise", C.c_float), ("noise_clip", C.c_float), ("td3bc_alpha", C.c_float), ("max_action", C.c_float),
+        ("update_actor_freq", C.c_int32),
+        ("num_critics", C.c_int32), ("eta", C.c_float),
+        ("external_arena", C.c_void_p),
+    ]
+
+
+class OrlBatch(C.Structure):
+    _fields_ = [("observations", C.c_void_p), ("actions", C.c_void_p), ("next_observations", C.c_void_p),
+                ("rewards", C.c_void_p), ("terminals", C.c_void_p), ("on_device", C.c_int32)]
+
+
+class OrlNoise(C.Structure):
+    _fields_ = [("slot", C.c_void_p * MAX_NOISE), ("on_device", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the engine; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"native update engine not built: {p} is missing "
+                           f"(run `python offlinerl-kit_amd/build.py` or __graft_entry__.build())")
+    lib = C.CDLL(p)
+    lib.orl_last_error.restype = C.c_char_p
+    lib.orl_version.restype = C.c_char_p
+    lib.orl_config_default.argtypes = [C.POINTER(OrlConfig), C.c_int32]
+    lib.orl_config_default.restype = None
+    lib.orl_arena_floats.argtypes = [C.POINTER(OrlConfig)]
+    lib.orl_arena_floats.restype = C.c_int64
+    lib.orl_engine_create.argtypes = [C.POINTER(OrlConfig), C.POINTER(C.c_void_p)]
+    lib.orl_engine_destroy.argtypes = [C.c_void_p]
+    lib.orl_engine_destroy.restype = None
+    lib.orl_engine_sync.argtypes = [C.c_void_p]
+    lib.orl_net_present.argtypes = [C.c_void_p, C.c_int]
+    lib.orl_net_floats.argtypes = [C.c_void_p, C.c_int]
+    lib.orl_net_floats.restype = C.c_int64
+    lib.orl_net_num_tensors.argtypes = [C.c_void_p, C.c_int]
+    lib.orl_net_tensor.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                   C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.orl_net_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.orl_net_ptr.restype = C.c_void_p
+    lib.orl_net_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    lib.orl_net_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
+    lib.orl_scalar_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+    lib.orl_scalar_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.orl_set_lr.argtypes = [C.c_void_p, C.c_int, C.c_float]
+    lib.orl_reset_optimizers.argtypes = [C.c_void_p]
+    lib.orl_buffer_load.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64]
+    lib.orl_buffer_normalize_obs.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    lib.orl_buffer_sample.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OrlBatch)]
+    lib.orl_buffer_size.argtypes = [C.c_void_p]
+    lib.orl_buffer_size.restype = C.c_int64
+    lib.orl_step.argtypes = [C.c_void_p, C.POINTER(OrlBatch), C.POINTER(OrlNoise), C.c_void_p]
+    lib.orl_learn_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    lib.orl_num_metrics.argtypes = [C.c_void_p]
+    lib.orl_metric_name.argtypes = [C.c_void_p, C.c_int]
+    lib.orl_metric_name.restype = C.c_char_p
+    lib.orl_step_count.argtypes = [C.c_void_p]
+    lib.orl_step_count.restype = C.c_int64
+    lib.orl_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.orl_debug_read.restype = C.c_int64
+    lib.orl_debug_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_int, C.c_int]
+    lib.orl_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.orl_profile_query.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().orl_last_error().decode()
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {last_error()}")
+
+
+def default_config(algo: str, **over) -> OrlConfig:
+    lib = load_library()
+    cfg = OrlConfig()
+    lib.orl_config_default(C.byref(cfg), ALGO_ID[algo])
+    apply_config(cfg, over)
+    return cfg
+
+
+def apply_config(cfg: OrlConfig, over: Dict) -> None:
+    names = {f[0] for f in OrlConfig._fields_}
+    for k, v in over.items():
+        if k == "hidden":
+            cfg.n_hidden = len(v)
+            for i, h in enumerate(v):
+                cfg.hidden[i] = int(h)
+        elif k in names:
+            setattr(cfg, k, v)
+        else:
+            raise KeyError(f"unknown engine config field {k!r}")
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine:
+    """Thin RAII wrapper over ``orl_engine*``."""
+
+    def __init__(self, cfg: OrlConfig):
+        self.lib = load_library()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _check(self.lib.orl_engine_create(C.byref(cfg), C.byref(self._h)), "orl_engine_create")
+        self.n_runs = cfg.n_runs
+        self.metric_names = [self.lib.orl_metric_name(self._h, i).decode() for i in range(self.lib.orl_num_metrics(self._h))]
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.orl_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ----
+    def net_present(self, net: int) -> bool:
+        return bool(self.lib.orl_net_present(self._h, net))
+
+    def net_tensors(self, net: int):
+        out = []
+        for i in range(self.lib.orl_net_num_tensors(self._h, net)):
+            name = C.create_string_buffer(128)
+            off, ndim, shape = C.c_int64(), C.c_int32(), (C.c_int64 * 4)()
+            _check(self.lib.orl_net_tensor(self._h, net, i, name, 128, C.byref(off), C.byref(ndim), shape), "orl_net_tensor")
+            out.append((name.value.decode(), off.value, tuple(shape[k] for k in range(ndim.value))))
+        return out
+
+    def net_floats(self, net: int) -> int:
+        return self.lib.orl_net_floats(self._h, net)
+
+    def net_ptr(self, run: int, net: int) -> int:
+        return self.lib.orl_net_ptr(self._h, run, net)
+
+    def set_net(self, run: int, net: int, params: Dict[str, np.ndarray]):
+        flat = np.zeros(self.net_floats(net), dtype=np.float32)
+        seen = set()
+        for name, off, shape in self.net_tensors(net):
+            if name not in params:
+                raise KeyError(f"missing parameter {name}")
+            a = _f32(params[name])
+            if a.size != int(np.prod(shape)):
+                raise ValueError(f"{name}: expected shape {shape}, got {a.shape}")
+            flat[off:off + a.size] = a.ravel()
+            seen.add(name)
+        _check(self.lib.orl_net_set(self._h, run, net, flat.ctypes.data, flat.size), "orl_net_set")
+
+    def get_net(self, run: int, net: int) -> Dict[str, np.ndarray]:
+        flat = np.empty(self.net_floats(net), dtype=np.float32)
+        _check(self.lib.orl_net_get(self._h, run, net, flat.ctypes.data, flat.size), "orl_net_get")
+        return {name: flat[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.net_tensors(net)}
+
+    def set_scalar(self, run: int, which: int, v: float):
+        _check(self.lib.orl_scalar_set(self._h, run, which, float(v)), "orl_scalar_set")
+
+    def get_scalar(self, run: int, which: int) -> float:
+        v = C.c_float()
+        _check(self.lib.orl_scalar_get(self._h, run, which, C.byref(v)), "orl_scalar_get")
+        return v.value
+
+    def set_lr(self, opt: int, lr: float):
+        _check(self.lib.orl_set_lr(self._h, opt, float(lr)), "orl_set_lr")
+
+    def reset_optimizers(self):
+        _check(self.lib.orl_reset_optimizers(self._h), "orl_reset_optimizers")
+
+    # ---- buffer ----
+    def buffer_load(self, obs, act, next_obs, rew, term):
+        obs, act, next_obs = _f32(obs), _f32(act), _f32(next_obs)
+        rew, term = _f32(rew).ravel(), _f32(term).ravel()
+        n = obs.shape[0]
+        _check(self.lib.orl_buffer_load(self._h, obs.ctypes.data, act.ctypes.data, next_obs.ctypes.data,
+                                        rew.ctypes.data, term.ctypes.data, n), "orl_buffer_load")
+
+    def buffer_sample(self, idx: Optional[np.ndarray] = None) -> OrlBatch:
+        out = OrlBatch()
+        p = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int64)
+            p = idx.ctypes.data
+        _check(self.lib.orl_buffer_sample(self._h, p, C.byref(out)), "orl_buffer_sample")
+        return out
+
+    # ---- hot path ----
+    def step(self, batch: Optional[Dict[str, np.ndarray]], noise: Optional[List[np.ndarray]], on_device=False) -> np.ndarray:
+        """batch/noise: host arrays with a leading run dimension (or raw device pointers when on_device)."""
+        keep = []
+        bp = None
+        if batch is not None:
+            b = OrlBatch()
+            for k in ("observations", "actions", "next_observations", "rewards", "terminals"):
+                v = batch[k]
+                if on_device:
+                    setattr(b, k, int(v))
+                else:
+                    a = _f32(v)
+                    keep.append(a)
+                    setattr(b, k, a.ctypes.data)
+            b.on_device = 1 if on_device else 0
+            bp = C.byref(b)
+        npz = None
+        if noise is not None:
+            n = OrlNoise()
+            for i, v in enumerate(noise):
+                if on_device:
+                    n.slot[i] = int(v)
+                else:
+                    a = _f32(v)
+                    keep.append(a)
+                    n.slot[i] = a.ctypes.data
+            n.on_device = 1 if on_device else 0
+            npz = C.byref(n)
+        m = np.zeros((self.n_runs, MAX_METRICS), dtype=np.float32)
+        _check(self.lib.orl_step(self._h, bp, npz, m.ctypes.data), "orl_step")
+        return m[:, :len(self.metric_names)]
+
+    def learn_n(self, n_steps: int):
+        m = np.zeros((self.n_runs, MAX_METRICS), dtype=np.float32)
+        ms = C.c_float()
+        _check(self.lib.orl_learn_n(self._h, n_steps, m.ctypes.data, C.byref(ms)), "orl_learn_n")
+        return m[:, :len(self.metric_names)], ms.value
+
+    def step_count(self) -> int:
+        return self.lib.orl_step_count(self._h)
+
+    def debug_read(self, run: int, name: str, cap: int = 1 << 22) -> np.ndarray:
+        buf = np.empty(cap, dtype=np.float32)
+        n = self.lib.orl_debug_read(self._h, run, name.encode(), buf.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError(f"orl_debug_read({name}) failed: {last_error()}")
+        return buf[:n].copy()
+
+    def profile_enable(self, on: bool):
+        self.lib.orl_profile_enable(self._h, 1 if on else 0)
+
+    def profile_table(self):
+        rows = []
+        i = 0
+        while True:
+            name = C.create_string_buffer(128)
+            tot, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
+            rc = self.lib.orl_profile_query(self._h, i, name, 128, C.byref(tot), C.byref(cnt), C.byref(fl))
+            if rc != 0:
+                break
+            rows.append(dict(name=name.value.decode(), total_ms=tot.value, launches=cnt.value, flops_per_launch=fl.value))
+            i += 1
+        return rows
+
+
+def debug_gemm(cfg: int, mode: int, A, B, v0=None, v1=None, ksplit=1, precision=0, M=None, N=None, K=None) -> np.ndarray:
+    """Kernel unit-test entry (orl_debug_gemm)."""
+    lib = load_library()
+    A, B = _f32(A), _f32(B)
+    wg = mode in (2, 4)
+    out = np.zeros(M * (N + 1) if wg else M * N, dtype=np.float32)
+    p0 = _f32(v0) if v0 is not None else None
+    p1 = _f32(v1) if v1 is not None else None
+    _check(lib.orl_debug_gemm(cfg, mode, M, N, K, A.ctypes.data, B.ctypes.data,
+                              p0.ctypes.data if p0 is not None else None, p1.ctypes.data if p1 is not None else None,
+                              out.ctypes.data, ksplit, precision), "orl_debug_gemm")
+    return out
