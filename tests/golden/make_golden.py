@@ -217,7 +217,92 @@ def gen_cql(ref, case):
     return out
 
 
-GENERATORS = {"cql": (gen_cql, list(synth.CQL_CASES))}
+
+# ----------------------------------------------------------------------------
+# IQL
+# ----------------------------------------------------------------------------
+
+def gen_iql(ref, case):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import iql as oiql
+    c, st, batches, _ = synth.iql_case_inputs(case)
+    cfg = oiql.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    actor = ref.ActorProb(ref.MLP(od, hid), ref.DiagGaussian(hid[-1], ad, unbounded=False, conditioned_sigma=False))
+    q1, q2, v = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od, hid))
+    _load(actor, st["actor"]); _load(q1, st["critic_q1"]); _load(q2, st["critic_q2"]); _load(v, st["critic_v"])
+    pol = ref.IQLPolicy(actor, q1, q2, v, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                        torch.optim.Adam(q1.parameters(), lr=cfg["critic_q_lr"]), torch.optim.Adam(q2.parameters(), lr=cfg["critic_q_lr"]),
+                        torch.optim.Adam(v.parameters(), lr=cfg["critic_v_lr"]), action_space=_ActionSpace(ad), tau=cfg["tau"],
+                        gamma=cfg["gamma"], expectile=cfg["expectile"], temperature=cfg["temperature"])
+    _load(pol.critic_q1_old, st["critic_q1_old"]); _load(pol.critic_q2_old, st["critic_q2_old"])
+    pol.train()
+    rq1, rv = CallRecorder(pol.critic_q1), CallRecorder(pol.critic_v)
+    out = OrderedDict(); full = "tiny" in case; keys = None
+    for k, b in enumerate(batches):
+        rq1.outs.clear(); rv.outs.clear()
+        res = pol.learn(_tb(b))
+        keys = keys or list(res.keys())
+        out[f"step{k}/losses"] = np.array([res[x] for x in keys], dtype=np.float64)
+        if k == 0:
+            out["step0/q1"] = rq1.outs[0]
+            out["step0/v"] = rv.outs[0]            # V(s) before the V update
+            out["step0/next_v"] = rv.outs[1]       # V_new(s')
+        if k in (0, len(batches) - 1):
+            for nm, mod in (("actor", pol.actor), ("critic_q1", pol.critic_q1), ("critic_q2", pol.critic_q2), ("critic_v", pol.critic_v),
+                            ("critic_q1_old", pol.critic_q1_old), ("critic_q2_old", pol.critic_q2_old)):
+                _put_state(out, f"state{k}/{nm}", _state_of(mod), full)
+    out["loss_keys"] = np.array(keys)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# TD3+BC
+# ----------------------------------------------------------------------------
+
+def gen_td3bc(ref, case):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import td3bc as otd
+    c, st, batches, noises = synth.td3bc_case_inputs(case)
+    cfg = otd.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    actor = ref.Actor(ref.MLP(od, hid), ad, max_action=cfg["max_action"])
+    c1, c2 = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid))
+    _load(actor, st["actor"]); _load(c1, st["critic1"]); _load(c2, st["critic2"])
+    pol = ref.TD3BCPolicy(actor, c1, c2, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                          torch.optim.Adam(c1.parameters(), lr=cfg["critic_lr"]), torch.optim.Adam(c2.parameters(), lr=cfg["critic_lr"]),
+                          tau=cfg["tau"], gamma=cfg["gamma"], max_action=cfg["max_action"], policy_noise=cfg["policy_noise"],
+                          noise_clip=cfg["noise_clip"], update_actor_freq=cfg["update_actor_freq"], alpha=cfg["alpha"], scaler=None)
+    _load(pol.actor_old, st["actor_old"]); _load(pol.critic1_old, st["critic1_old"]); _load(pol.critic2_old, st["critic2_old"])
+    pol.train()
+    r1 = CallRecorder(pol.critic1)
+    feeder = NoiseFeeder(); feeder.install()
+    out = OrderedDict(); full = "tiny" in case; keys = None
+    try:
+        for k, (b, n) in enumerate(zip(batches, noises)):
+            feeder.normal_q = [n["eps_target"]]
+            r1.outs.clear()
+            res = pol.learn(_tb(b))
+            assert not feeder.normal_q
+            keys = keys or list(res.keys())
+            out[f"step{k}/losses"] = np.array([res[x] for x in keys], dtype=np.float64)
+            if k == 0:
+                out["step0/q1"] = r1.outs[0]
+                out["step0/q_pi"] = r1.outs[1]
+            if k in (0, 1, len(batches) - 1):
+                for nm, mod in (("actor", pol.actor), ("critic1", pol.critic1), ("critic2", pol.critic2), ("actor_old", pol.actor_old),
+                                ("critic1_old", pol.critic1_old), ("critic2_old", pol.critic2_old)):
+                    _put_state(out, f"state{k}/{nm}", _state_of(mod), full)
+    finally:
+        feeder.uninstall()
+    out["loss_keys"] = np.array(keys)
+    return out
+
+
+GENERATORS = {"cql": (gen_cql, list(synth.CQL_CASES)), "iql": (gen_iql, list(synth.IQL_CASES)),
+              "td3bc": (gen_td3bc, list(synth.TD3BC_CASES))}
 
 
 def main(argv):

@@ -187,3 +187,51 @@ def cql_case_inputs(case):
     batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
     noises = [make_cql_noise(rng, c["B"], c["N"], ad, max_q_backup=mq) for _ in range(c["steps"])]
     return c, state, batches, noises
+
+
+IQL_CASES = {
+    "iql_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=5, seed=201, over={}),
+    "iql_tiny_h3": dict(obs_dim=4, act_dim=2, hidden=[32, 32, 32], B=8, steps=3, seed=202, over=dict(expectile=0.9, temperature=1.0)),
+    "iql_hopper": dict(obs_dim=11, act_dim=3, hidden=[256, 256], B=256, steps=20, seed=21, over={}),
+}
+
+TD3BC_CASES = {
+    "td3bc_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=6, seed=301, over={}),
+    "td3bc_tiny_freq3": dict(obs_dim=4, act_dim=2, hidden=[32, 32], B=8, steps=7, seed=302, over=dict(update_actor_freq=3)),
+    "td3bc_halfcheetah": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, steps=20, seed=31, over={}),
+}
+
+
+def _perturbed(rng, net, s=0.01):
+    return OrderedDict((n, (v + s * rng.standard_normal(v.shape)).astype(f32)) for n, v in net.items())
+
+
+def iql_case_inputs(case):
+    c = IQL_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    st = OrderedDict()
+    st["actor"] = make_gauss_actor(rng, od, ad, hid)
+    st["critic_q1"] = make_critic(rng, od + ad, hid)
+    st["critic_q2"] = make_critic(rng, od + ad, hid)
+    st["critic_v"] = make_critic(rng, od, hid)
+    st["critic_q1_old"] = _perturbed(rng, st["critic_q1"])
+    st["critic_q2_old"] = _perturbed(rng, st["critic_q2"])
+    batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
+    return c, st, batches, [None] * c["steps"]
+
+
+def td3bc_case_inputs(case):
+    c = TD3BC_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    st = OrderedDict()
+    st["actor"] = make_det_actor(rng, od, ad, hid)
+    st["critic1"] = make_critic(rng, od + ad, hid)
+    st["critic2"] = make_critic(rng, od + ad, hid)
+    st["actor_old"] = _perturbed(rng, st["actor"])
+    st["critic1_old"] = _perturbed(rng, st["critic1"])
+    st["critic2_old"] = _perturbed(rng, st["critic2"])
+    batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
+    noises = [make_td3_noise(rng, c["B"], ad) for _ in range(c["steps"])]
+    return c, st, batches, noises

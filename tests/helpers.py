@@ -63,3 +63,16 @@ def check_state_against_golden(g, tag, nets, atol, rtol=1e-4):
                 worst = max(worst, ferr)
                 assert ferr <= atol + rtol * np.abs(g[fkey]).max(), (tag, nm, k, ferr)
     return worst
+
+
+def generic_oracle_setup(algo, case):
+    """(module, cfg, state, batches, noises) for iql / td3bc / edac cases."""
+    import importlib
+    mod = importlib.import_module(f"oracle.{algo}")
+    c, st, batches, noises = getattr(synth, f"{algo}_case_inputs")(case)
+    cfg = mod.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"])
+    cfg.update(c["over"])
+    st = clone_state(st)
+    mod.init_opt(st)
+    return mod, cfg, st, batches, noises

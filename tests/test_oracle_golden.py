@@ -34,3 +34,33 @@ def test_cql_oracle_matches_reference(case):
             if cfg["auto_alpha"]:
                 assert abs(float(st["log_alpha"][0]) - float(g[f"state{k}/log_alpha"][0])) < 1e-6
             assert abs(float(st["cql_log_alpha"][0]) - float(g[f"state{k}/cql_log_alpha"][0])) < 1e-6
+
+
+def _run_generic(algo, case, net_names, aux_checks):
+    from helpers import generic_oracle_setup
+    g = load_golden(case)
+    mod, cfg, st, batches, noises = generic_oracle_setup(algo, case)
+    keys = [str(k) for k in g["loss_keys"]]
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, aux = mod.learn(st, cfg, b, n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (case, k, got, g[f"step{k}/losses"])
+        if k == 0:
+            for okey, gkey in aux_checks:
+                if okey in aux:
+                    assert rel_err(aux[okey], g[gkey]) < 1e-4, (okey,)
+        if f"state{k}/{net_names[0]}/{next(iter(st[net_names[0]]))}/digest" in g.files:
+            check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in net_names}, atol=2e-6 * (k + 1))
+
+
+@pytest.mark.parametrize("case", list(synth.IQL_CASES))
+def test_iql_oracle_matches_reference(case):
+    _run_generic("iql", case, ("actor", "critic_q1", "critic_q2", "critic_v", "critic_q1_old", "critic_q2_old"),
+                 (("q1", "step0/q1"), ("v", "step0/v")))
+
+
+@pytest.mark.parametrize("case", list(synth.TD3BC_CASES))
+def test_td3bc_oracle_matches_reference(case):
+    _run_generic("td3bc", case, ("actor", "critic1", "critic2", "actor_old", "critic1_old", "critic2_old"),
+                 (("q1", "step0/q1"), ("q_pi", "step0/q_pi")))
