@@ -301,8 +301,55 @@ def gen_td3bc(ref, case):
     return out
 
 
+
+# ----------------------------------------------------------------------------
+# EDAC
+# ----------------------------------------------------------------------------
+
+def gen_edac(ref, case):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import edac as oed
+    c, st, batches, noises = synth.edac_case_inputs(case)
+    cfg = oed.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid, K = c["obs_dim"], c["act_dim"], c["hidden"], cfg["num_critics"]
+    actor = ref.ActorProb(ref.MLP(od, hid), ref.TanhDiagGaussian(hid[-1], ad, unbounded=True, conditioned_sigma=True))
+    critics = ref.EnsembleCritic(od, ad, hid, num_ensemble=K)
+    _load(actor, st["actor"]); _load(critics, st["critics"])
+    aopt = torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"])
+    copt = torch.optim.Adam(critics.parameters(), lr=cfg["critic_lr"])
+    log_alpha = torch.tensor(st["log_alpha"].copy(), requires_grad=True)
+    alpha = (cfg["target_entropy"], log_alpha, torch.optim.Adam([log_alpha], lr=cfg["alpha_lr"]))
+    pol = ref.EDACPolicy(actor, critics, aopt, copt, tau=cfg["tau"], gamma=cfg["gamma"], alpha=alpha,
+                         max_q_backup=cfg["max_q_backup"], deterministic_backup=cfg["deterministic_backup"], eta=cfg["eta"])
+    _load(pol.critics_old, st["critics_old"])
+    pol.train()
+    rc = CallRecorder(pol.critics)
+    feeder = NoiseFeeder(); feeder.install()
+    out = OrderedDict(); full = "tiny" in case; keys = None
+    try:
+        for k, (b, n) in enumerate(zip(batches, noises)):
+            feeder.normal_q = [n["eps_actor"], n["eps_next"]]
+            rc.outs.clear()
+            res = pol.learn(_tb(b))
+            assert not feeder.normal_q
+            keys = keys or list(res.keys())
+            out[f"step{k}/losses"] = np.array([res[x] for x in keys], dtype=np.float64)
+            if k == 0:
+                out["step0/qas"] = rc.outs[0]
+                out["step0/qs"] = rc.outs[1]
+            if k in (0, len(batches) - 1):
+                for nm, mod in (("actor", pol.actor), ("critics", pol.critics), ("critics_old", pol.critics_old)):
+                    _put_state(out, f"state{k}/{nm}", _state_of(mod), full)
+                out[f"state{k}/log_alpha"] = pol._log_alpha.detach().numpy().copy()
+    finally:
+        feeder.uninstall()
+    out["loss_keys"] = np.array(keys)
+    return out
+
+
 GENERATORS = {"cql": (gen_cql, list(synth.CQL_CASES)), "iql": (gen_iql, list(synth.IQL_CASES)),
-              "td3bc": (gen_td3bc, list(synth.TD3BC_CASES))}
+              "td3bc": (gen_td3bc, list(synth.TD3BC_CASES)), "edac": (gen_edac, list(synth.EDAC_CASES))}
 
 
 def main(argv):

@@ -235,3 +235,33 @@ def td3bc_case_inputs(case):
     batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
     noises = [make_td3_noise(rng, c["B"], ad) for _ in range(c["steps"])]
     return c, st, batches, noises
+
+
+EDAC_CASES = {
+    "edac_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=5, seed=401, over=dict(num_critics=4, eta=1.0)),
+    "edac_tiny_h3_eta5": dict(obs_dim=4, act_dim=2, hidden=[32, 32, 32], B=8, steps=3, seed=402, over=dict(num_critics=3, eta=5.0)),
+    "edac_tiny_eta0_det": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=3, seed=403,
+                               over=dict(num_critics=4, eta=0.0, deterministic_backup=True)),
+    "edac_tiny_maxq": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=8, steps=2, seed=404, over=dict(num_critics=3, eta=1.0, max_q_backup=True)),
+    "edac_walker2d": dict(obs_dim=17, act_dim=6, hidden=[256, 256, 256], B=256, steps=5, seed=41, over=dict(num_critics=10, eta=5.0)),
+}
+
+
+def edac_case_inputs(case):
+    c = EDAC_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    od, ad, hid, K = c["obs_dim"], c["act_dim"], c["hidden"], c["over"]["num_critics"]
+    st = OrderedDict()
+    st["actor"] = make_tanh_actor(rng, od, ad, hid)
+    st["critics"] = make_ensemble_critic(rng, od + ad, hid, K)
+    # larger last layer than the script's 3e-3 so the min over members / gradient penalty are well exercised
+    last = f"model.{2 * len(hid)}"
+    st["critics"][last + ".weight"] = _uniform(rng, st["critics"][last + ".weight"].shape, 0.1)
+    st["critics"][last + ".saved_weight"] = st["critics"][last + ".weight"].copy()
+    st["critics_old"] = OrderedDict((n, (v + (0.01 * rng.standard_normal(v.shape) if "saved" not in n else 0)).astype(f32))
+                                    for n, v in st["critics"].items())
+    st["log_alpha"] = np.array([-0.3], dtype=f32)
+    mq = bool(c["over"].get("max_q_backup", False))
+    batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
+    noises = [make_sac_noise(rng, c["B"], ad, rows_next=(10 * c["B"] if mq else None)) for _ in range(c["steps"])]
+    return c, st, batches, noises

@@ -32,6 +32,13 @@ def rel_err(a, b, floor=1e-3):
     return float((np.abs(a - b) / np.maximum(np.abs(b), floor * scale)).max())
 
 
+def scale_err(a, b):
+    """max |a-b| / max |b|: error relative to the tensor's scale (the 1e-4 gate for Q-value arrays)."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
 def cql_oracle_setup(case):
     from oracle import cql as ocql
     c, st, batches, noises = synth.cql_case_inputs(case)
