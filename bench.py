@@ -150,7 +150,9 @@ def main():
                                  num_repeat_actions=NREP, target_entropy=-float(ACT))
     eng = _engine.Engine(cfg)
     ds = make_dataset(rank, args.dataset_size)
-    eng.buffer_load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+    buf = _engine.DeviceBuffer(OBS, ACT, local_rank)
+    buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+    eng.attach_buffer(buf)
     for r in range(R):
         init_weights(eng, r, rank * R + r)
 

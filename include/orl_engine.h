@@ -147,16 +147,23 @@ int orl_scalar_get(orl_engine* e, int run, int which, float* v);
 int orl_set_lr(orl_engine* e, int opt, float lr);       /* optim.param_groups[0]["lr"] = lr */
 int orl_reset_optimizers(orl_engine* e);                /* fresh torch.optim.Adam state (step=0, m=v=0) */
 
-/* -- replay buffer (buffer/buffer.py) ------------------------------------------ */
-/* load_dataset (:72-86): host arrays -> HBM-resident SoA; obs/next_obs [n][obs_dim], act [n][act_dim], rew/term [n] */
-int orl_buffer_load(orl_engine* e, const float* obs, const float* act, const float* next_obs, const float* rew,
+/* -- replay buffer (buffer/buffer.py): its own object, like the reference's ReplayBuffer ------- */
+typedef struct orl_buffer orl_buffer;
+/* ReplayBuffer.__init__ (:8-32): an empty HBM-resident SoA store on `device` */
+int orl_buffer_create(int32_t obs_dim, int32_t act_dim, int32_t device, orl_buffer** out);
+void orl_buffer_destroy(orl_buffer* b);
+/* load_dataset (:72-86): host arrays -> HBM SoA; obs/next_obs [n][obs_dim], act [n][act_dim], rew/term [n] */
+int orl_buffer_load(orl_buffer* b, const float* obs, const float* act, const float* next_obs, const float* rew,
                     const float* term, int64_t n);
-/* normalize_obs (:88-94): in place on device; writes mean/std (obs_dim each) to host */
-int orl_buffer_normalize_obs(orl_engine* e, float eps, float* mean_out, float* std_out);
-/* sample (:96-106): gather rows idx[n_runs][batch] (host int64; NULL = device Philox indices) into the engine's
- * batch slots; out (optional) receives device pointers to the gathered, padded-free copies. */
-int orl_buffer_sample(orl_engine* e, const int64_t* idx, orl_batch* out);
-int64_t orl_buffer_size(orl_engine* e);
+/* normalize_obs (:88-94): (x - mean) / (std + eps) in place on the device; mean/std(+eps) (obs_dim each) to host */
+int orl_buffer_normalize_obs(orl_buffer* b, float eps, float* mean_out, float* std_out);
+int64_t orl_buffer_size(orl_buffer* b);
+/* sample (:96-106): gather `batch` rows into caller-owned DEVICE arrays (packed [batch][dim], rew/term [batch]).
+ * idx: host int64[batch] (the np.random.randint draw of the reference) or NULL = device Philox(seed, call counter). */
+int orl_buffer_sample(orl_buffer* b, const int64_t* idx, int32_t batch, uint64_t seed, float* obs_out, float* act_out,
+                      float* next_obs_out, float* rew_out, float* term_out);
+/* lets orl_learn_n sample this buffer on the device (the buffer must outlive the engine's use of it) */
+int orl_engine_attach_buffer(orl_engine* e, orl_buffer* b);
 
 /* -- the hot path ---------------------------------------------------------------- */
 /* policy.learn(batch) with explicit noise: one gradient step for every run.

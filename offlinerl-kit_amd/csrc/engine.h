@@ -13,6 +13,7 @@
 namespace orl {
 
 void set_error(const std::string& msg);
+int fail(const std::string& msg);
 #define ORL_HIP(expr)                                                                            \
   do {                                                                                           \
     hipError_t _e = (expr);                                                                      \
@@ -29,33 +30,44 @@ struct TensorInfo {
   long shape[4];
 };
 
-// A network = MLP backbone of L ReLU layers + one linear "tail" (critic last / actor head).
+// A network (family) = MLP of L ReLU layers + one linear tail (critic last / actor head).
+// `members` identical nets are batched through blockIdx.z.  Two storage layouts:
+//   ens = false : nn.Linear, W (out,in), every member is its own contiguous block (member stride = size)
+//   ens = true  : EnsembleLinear (nets/ensemble_linear.py:9-41), W (K,in,out), b (K,1,out): member k of layer l
+//                 lives at w_off[l] + k*in*out
 struct NetLayout {
   bool present = false;
+  bool ens = false;
+  int members = 1;
   int in_dim = 0, L = 0, out_dim = 0;
-  int H[ORL_MAX_HIDDEN + 1] = {0};       // hidden widths
+  int H[ORL_MAX_HIDDEN + 1] = {0};
   long w_off[ORL_MAX_HIDDEN + 1] = {0};  // layers 0..L-1 hidden, layer L = tail
   long b_off[ORL_MAX_HIDDEN + 1] = {0};
+  long w_ms[ORL_MAX_HIDDEN + 1] = {0};   // member strides
+  long b_ms[ORL_MAX_HIDDEN + 1] = {0};
   long extra_off = -1;                   // IQL sigma_param
-  long size = 0;
+  long size = 0;                         // floats of ONE net (ens: of the whole ensemble)
   std::vector<TensorInfo> tensors;
   int layer_in(int l) const { return l == 0 ? in_dim : H[l - 1]; }
   int layer_out(int l) const { return l == L ? out_dim : H[l]; }
 };
 
-// matrix / vector views batched over (run, net)
+// matrix / vector views batched over (run, member)
 struct Mat {
   float* p = nullptr;
-  long rs = 0, cs = 0;  // run stride, net stride (elements)
+  long rs = 0, cs = 0;  // run stride, member stride (elements)
   int pitch = 0;
   Mat rows(long r0) const { Mat m = *this; m.p = p + r0 * pitch; return m; }
   Mat cols(int c0) const { Mat m = *this; m.p = p + c0; return m; }
   Mat net(int c) const { Mat m = *this; m.p = p + c * cs; return m; }
+  Mat shared() const { Mat m = *this; m.cs = 0; return m; }
 };
-struct NetRef {           // parameters of a (run, net)-batched family with identical layout
-  float* base = nullptr;  // params of run 0, net 0
-  long rs = 0, cs = 0;
+struct NetRef {
+  float* base = nullptr;  // params of run 0, member 0
+  long rs = 0;            // run stride
+  long g_off = 0;         // offset of the family's gradients inside a run's gradient slab
   const NetLayout* lay = nullptr;
+  int nz1 = 1;            // members driven by a launch
 };
 
 struct ProfEntry {
@@ -64,19 +76,28 @@ struct ProfEntry {
   hipEvent_t a, b;
 };
 
+struct Buffer {             // HBM-resident replay buffer (buffer/buffer.py)
+  int dev = 0, od = 0, ad = 0, OP = 0, AP = 0;
+  long n = 0;
+  float *obs = nullptr, *nobs = nullptr, *act = nullptr, *rew = nullptr, *term = nullptr;
+  long long* idx = nullptr; long idx_cap = 0;
+  unsigned long long counter = 0;
+  ~Buffer();
+};
+
+struct DY;  // backward seed description (engine.hip)
+
 struct Engine {
   orl_config cfg;
   int dev = 0;
   hipStream_t stream = nullptr;
-  int R = 1, B = 0, N = 0, od = 0, ad = 0, OP = 0, AP = 0, XP = 0, L = 0, Hlast = 0;
+  int R = 1, B = 0, N = 0, od = 0, ad = 0, OP = 0, AP = 0, XP = 0, L = 0, K = 2;
   NetLayout lay[ORL_NUM_NETS];
-  // arenas
   float* arena = nullptr;      // [R][P_train] then [R][P_tgt]
-  bool arena_owned = false;
   long P_train = 0, P_tgt = 0;
-  long net_off[ORL_NUM_NETS];  // offset inside the run's trainable (or target) block
+  long net_off[ORL_NUM_NETS];
   bool net_is_target[ORL_NUM_NETS];
-  float* adam_m = nullptr;     // [R][P_train]
+  float* adam_m = nullptr;
   float* adam_v = nullptr;
   float* grads = nullptr;      // [R][max_slab][P_train]
   int max_slab = 32;
@@ -88,50 +109,54 @@ struct Engine {
   float *metrics_last = nullptr, *metrics_sum = nullptr;
   int nm = 0;
   std::vector<std::string> metric_names;
-  // replay buffer (HBM-resident SoA)
-  float *d_obs = nullptr, *d_nobs = nullptr, *d_act = nullptr, *d_rew = nullptr, *d_term = nullptr;
-  long n_data = 0;
-  long long* d_idx = nullptr;  // [R][B]
-  // workspace
+  Buffer* buf = nullptr;       // attached replay buffer (not owned)
   std::vector<void*> allocs;
-  std::map<std::string, Mat> ws;      // named buffers
-  std::map<std::string, long> ws_len; // floats per run
-  // debug taps: name -> (matrix, rows, cols)
+  std::map<std::string, Mat> ws;
+  std::map<std::string, long> ws_len;
   struct Tap { Mat m; long rows; int cols; };
   std::map<std::string, Tap> taps;
-  // profiling
+  struct NoiseSlot { std::string name; int kind; int rows; };
+  std::vector<NoiseSlot> noise_slots;
   bool prof_on = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
-  // graph
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  hipGraph_t graph[2] = {nullptr, nullptr};
   bool use_graph = true;
 
   ~Engine();
   int init(const orl_config& c);
   Mat alloc(const std::string& name, long rows, int pitch, int nets = 1);
+  Mat& W(const std::string& n) { return ws.at(n); }
   float* raw_alloc(size_t bytes);
   float* net_ptr(int run, int net) const;
-  NetRef net_ref(int net) const;  // family starting at `net` (critic1 -> {critic1,critic2})
+  NetRef net_ref(int net, int members) const;
+  MetricsP mp() const { return MetricsP{metrics_last, metrics_sum, nm}; }
 
   // launch helpers (enqueue on stream)
-  int linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, bool relu, int nz1, const char* tag);
-  int linear_dgrad(const Mat& dY, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH,
-                   const Mat& dX, int nz1, const char* tag, const Mat* rank1_H = nullptr, const Mat* rowv = nullptr);
-  int linear_wgrad(const Mat& dY, const Mat& X, int M, const NetRef& nr, int layer, long g_net_off, int ksplit,
-                   int nz1, const char* tag, const Mat* rank1_H = nullptr, const Mat* rowv = nullptr);
-  int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, bool polyak, int target_net,
-           unsigned long long t_div = 1);
+  int linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH, const char* tag,
+                 int in_row0 = 0, int in_rows = -1);
+  int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag);
+  int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
+                   const char* tag, int in_row0 = 0, int in_rows = -1);
+  int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
+  int polyak(int target_net, int src_net, int nnets);
   void prof_begin(const char* name, double flops);
   void prof_end();
+  int assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep);
+  int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
 
-  int enqueue_sample(const long long* idx_dev);
+  int enqueue_sample();
   int enqueue_noise();
-  int enqueue_step();
-  int cql_build();
-  int cql_step();
+  int enqueue_step(int variant);
+  int step_variant() const;
+  int n_variants() const;
+  int build_common();
+  int cql_build(); int cql_step();
+  int iql_build(); int iql_step();
+  int td3bc_build(); int td3bc_step(bool actor_step);
+  int edac_build(); int edac_step();
 };
 
 }  // namespace orl

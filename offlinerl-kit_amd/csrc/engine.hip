@@ -1,4 +1,5 @@
-// engine.hip — MI355X-native update engine: host side (arenas, launch schedule) + C ABI.
+// engine.hip — MI355X-native update engine: host side (arenas, launch helpers, ABI).
+// Algorithm schedules live in algo_*.inc (same translation unit).
 // Build: hipcc -O3 --offload-arch=gfx950 -fPIC -shared engine.hip -o liborlengine.so
 #include "engine.h"
 
@@ -7,13 +8,13 @@
 #include <string.h>
 
 #include <algorithm>
+#include <tuple>
 
 namespace orl {
 
 static thread_local std::string g_err;
 void set_error(const std::string& msg) { g_err = msg; }
-
-static int fail(const std::string& msg) {
+int fail(const std::string& msg) {
   set_error(msg);
   return -1;
 }
@@ -78,6 +79,29 @@ static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind 
     l.b_off[L] = off; add_tensor(l, "last.bias", off, {act_dim}); off += act_dim;
   }
   l.size = off;
+  for (int i = 0; i <= L; ++i) l.w_ms[i] = l.b_ms[i] = l.size;
+  return l;
+}
+
+// EnsembleCritic (modules/ensemble_critic_module.py:11-31): model.{0,2,..}.weight (K,in,out), .bias (K,1,out)
+static NetLayout make_ensemble_layout(int in_dim, const int* hidden, int L, int K) {
+  NetLayout l;
+  l.present = true; l.ens = true; l.members = K;
+  l.in_dim = in_dim; l.L = L; l.out_dim = 1;
+  long off = 0;
+  int d = in_dim;
+  for (int i = 0; i <= L; ++i) {
+    const int o = (i == L) ? 1 : hidden[i];
+    if (i < L) l.H[i] = hidden[i];
+    l.w_off[i] = off; l.w_ms[i] = (long)d * o;
+    add_tensor(l, "model." + std::to_string(2 * i) + ".weight", off, {K, d, o});
+    off += (long)K * d * o;
+    l.b_off[i] = off; l.b_ms[i] = o;
+    add_tensor(l, "model." + std::to_string(2 * i) + ".bias", off, {K, 1, o});
+    off += (long)K * o;
+    d = o;
+  }
+  l.size = off;
   return l;
 }
 
@@ -85,29 +109,57 @@ static int build_layouts(const orl_config& c, NetLayout* lay, long* net_off, boo
   for (int i = 0; i < ORL_NUM_NETS; ++i) { lay[i] = NetLayout(); net_off[i] = 0; is_tgt[i] = false; }
   if (c.n_hidden < 1 || c.n_hidden > ORL_MAX_HIDDEN) return fail("n_hidden must be in [1,4]");
   if (c.obs_dim < 1 || c.act_dim < 1 || c.batch_size < 1 || c.n_runs < 1) return fail("bad dims");
+  if (c.act_dim > 32) return fail("act_dim > 32 not supported");
+  const int od = c.obs_dim, ad = c.act_dim, L = c.n_hidden;
+  const NetLayout crit = make_mlp_layout(od + ad, c.hidden, L, TAIL_CRITIC, ad);
+  long o = 0, t = 0;
+  auto train = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = o; o += l.size; };
+  auto target = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = t; is_tgt[id] = true; t += l.size; };
   if (c.algo == ORL_ALGO_CQL) {
-    lay[ORL_NET_ACTOR] = make_mlp_layout(c.obs_dim, c.hidden, c.n_hidden, TAIL_TANH_GAUSS, c.act_dim);
-    NetLayout cr = make_mlp_layout(c.obs_dim + c.act_dim, c.hidden, c.n_hidden, TAIL_CRITIC, c.act_dim);
-    lay[ORL_NET_CRITIC1] = lay[ORL_NET_CRITIC2] = lay[ORL_NET_CRITIC1_OLD] = lay[ORL_NET_CRITIC2_OLD] = cr;
-    long o = 0;
-    net_off[ORL_NET_ACTOR] = o; o += lay[ORL_NET_ACTOR].size;
-    net_off[ORL_NET_CRITIC1] = o; o += cr.size;
-    net_off[ORL_NET_CRITIC2] = o; o += cr.size;
-    *P_train = o;
-    net_off[ORL_NET_CRITIC1_OLD] = 0; net_off[ORL_NET_CRITIC2_OLD] = cr.size;
-    is_tgt[ORL_NET_CRITIC1_OLD] = is_tgt[ORL_NET_CRITIC2_OLD] = true;
-    *P_tgt = 2 * cr.size;
-    return 0;
+    train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_TANH_GAUSS, ad));
+    train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
+    target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
+  } else if (c.algo == ORL_ALGO_IQL) {
+    train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_GAUSS, ad));
+    train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
+    train(ORL_NET_CRITIC_V, make_mlp_layout(od, c.hidden, L, TAIL_CRITIC, ad));
+    target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
+  } else if (c.algo == ORL_ALGO_TD3BC) {
+    const NetLayout act = make_mlp_layout(od, c.hidden, L, TAIL_DET, ad);
+    train(ORL_NET_ACTOR, act);
+    train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
+    target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
+    target(ORL_NET_ACTOR_OLD, act);
+  } else if (c.algo == ORL_ALGO_EDAC) {
+    if (c.num_critics < 2 || c.num_critics > 64) return fail("num_critics must be in [2,64]");
+    train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_TANH_GAUSS, ad));
+    const NetLayout ens = make_ensemble_layout(od + ad, c.hidden, L, c.num_critics);
+    train(ORL_NET_CRITIC1, ens);
+    target(ORL_NET_CRITIC1_OLD, ens);
+  } else {
+    return fail("unknown algorithm id");
   }
-  return fail("algorithm not built into this engine yet (CQL only)");
+  *P_train = o; *P_tgt = t;
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Engine
+// Buffer
+// ---------------------------------------------------------------------------------------------
+Buffer::~Buffer() {
+  hipSetDevice(dev);
+  for (float* p : {obs, nobs, act, rew, term}) if (p) hipFree(p);
+  if (idx) hipFree(idx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Engine basics
 // ---------------------------------------------------------------------------------------------
 Engine::~Engine() {
-  if (graph_exec) hipGraphExecDestroy(graph_exec);
-  if (graph) hipGraphDestroy(graph);
+  for (int i = 0; i < 2; ++i) {
+    if (graph_exec[i]) hipGraphExecDestroy(graph_exec[i]);
+    if (graph[i]) hipGraphDestroy(graph[i]);
+  }
   for (auto& e : ev_pool) hipEventDestroy(e);
   for (void* p : allocs) hipFree(p);
   if (stream) hipStreamDestroy(stream);
@@ -141,12 +193,13 @@ float* Engine::net_ptr(int run, int net) const {
   return arena + (long)run * P_train + net_off[net];
 }
 
-NetRef Engine::net_ref(int net) const {
+NetRef Engine::net_ref(int net, int members) const {
   NetRef r;
   r.base = net_ptr(0, net);
   r.rs = net_is_target[net] ? P_tgt : P_train;
-  r.cs = lay[net].size;
+  r.g_off = net_off[net];
   r.lay = &lay[net];
+  r.nz1 = members;
   return r;
 }
 
@@ -170,6 +223,14 @@ void Engine::prof_end() {
   hipEventRecord(prof.back().b, stream);
 }
 
+#define ORL_LAUNCH(tag, kernel, grid, block, ...)                                      \
+  do {                                                                                 \
+    prof_begin(tag, 0);                                                                \
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                   \
+    prof_end();                                                                        \
+    if (hipGetLastError() != hipSuccess) return fail(std::string(tag) + ": launch failed"); \
+  } while (0)
+
 template <int PA, int PB, int EPI>
 static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
@@ -180,45 +241,61 @@ static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag)
   return 0;
 }
 
-int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, bool relu, int nz1, const char* tag) {
+// gradient w.r.t. a layer output [M x out].  rank1: dz = (H > 0) ? rowv[m] * w_tail[n] : 0 (never materialised)
+struct DY {
+  bool rank1 = false;
+  Mat m;     // plain: the gradient matrix ; rank1: post-ReLU activation H of the top hidden layer
+  Mat rowv;  // rank1: dLoss/dq per row
+  static DY plain(const Mat& m) { DY d; d.m = m; return d; }
+  static DY virt(const Mat& H, const Mat& dq) { DY d; d.rank1 = true; d.m = H; d.rowv = dq; return d; }
+};
+
+int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH,
+                       const char* tag, int in_row0, int in_rows) {
   const NetLayout& l = *nr.lay;
+  const int in = l.layer_in(layer), out = l.layer_out(layer);
+  if (in_rows < 0) in_rows = in;
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.A = {X.p, X.rs, X.cs};
   p.a_sr = X.pitch; p.a_sk = 1;
-  p.B = {nr.base + l.w_off[layer], nr.rs, nr.cs};
-  p.b_sr = l.layer_in(layer); p.b_sk = 1;
-  p.C = Y.p; p.c_s0 = Y.rs; p.c_s1 = Y.cs; p.c_sr = Y.pitch;
-  p.M = M; p.N = l.layer_out(layer); p.K = l.layer_in(layer);
-  p.nz1 = nz1; p.ksplit = 1;
-  p.bias = {nr.base + l.b_off[layer], nr.rs, nr.cs};
-  const int nz = R * nz1;
-  if (relu) return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, CFG_AUTO, p, nz, tag);
-  return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS>(this, CFG_AUTO, p, nz, tag);
+  if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)in_row0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = out; }
+  else { p.B = {nr.base + l.w_off[layer] + in_row0, nr.rs, l.w_ms[layer]}; p.b_sr = in; p.b_sk = 1; }
+  p.C = Y.p; p.c_s0 = Y.rs; p.c_s1 = Y.cs; p.c_sr = Y.pitch; p.c_sn = 1;
+  p.M = M; p.N = out; p.K = in_rows;
+  p.nz1 = nr.nz1; p.ksplit = 1;
+  p.bias = {nr.base + l.b_off[layer], nr.rs, l.b_ms[layer]};
+  if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
+  const int nz = R * nr.nz1;
+  switch (epi) {
+    case E_BIAS_RELU: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, CFG_AUTO, p, nz, tag);
+    case E_BIAS: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS>(this, CFG_AUTO, p, nz, tag);
+    case E_MASK: return run_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
+    default: return run_gemm<PA_PLAIN, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
+  }
 }
 
-int Engine::linear_dgrad(const Mat& dY, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH,
-                         const Mat& dX, int nz1, const char* tag, const Mat* rank1_H, const Mat* rowv) {
+int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH,
+                         const Mat& dX, const char* tag) {
   const NetLayout& l = *nr.lay;
+  const int in = l.layer_in(layer), out = l.layer_out(layer);
   GemmP p;
   memset(&p, 0, sizeof(p));
-  if (rank1_H) {
-    p.A = {rank1_H->p, rank1_H->rs, rank1_H->cs};
-    p.a_sr = rank1_H->pitch; p.a_sk = 1; p.a_trans = 0;
-    p.rowv = {rowv->p, rowv->rs, rowv->cs};
-    p.colv = {nr.base + l.w_off[l.L], nr.rs, nr.cs};
-  } else {
-    p.A = {dY.p, dY.rs, dY.cs};
-    p.a_sr = dY.pitch; p.a_sk = 1;
+  p.A = {dy.m.p, dy.m.rs, dy.m.cs};
+  p.a_sr = dy.m.pitch; p.a_sk = 1;
+  if (dy.rank1) {
+    p.a_trans = 0;
+    p.rowv = {dy.rowv.p, dy.rowv.rs, dy.rowv.cs};
+    p.colv = {nr.base + l.w_off[l.L], nr.rs, l.w_ms[l.L]};
   }
-  p.B = {nr.base + l.w_off[layer] + col0, nr.rs, nr.cs};
-  p.b_sr = 1; p.b_sk = l.layer_in(layer);
-  p.C = dX.p; p.c_s0 = dX.rs; p.c_s1 = dX.cs; p.c_sr = dX.pitch;
-  p.M = M; p.N = ncols; p.K = l.layer_out(layer);
-  p.nz1 = nz1; p.ksplit = 1;
+  if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)col0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = out; p.b_sk = 1; }
+  else { p.B = {nr.base + l.w_off[layer] + col0, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = in; }
+  p.C = dX.p; p.c_s0 = dX.rs; p.c_s1 = dX.cs; p.c_sr = dX.pitch; p.c_sn = 1;
+  p.M = M; p.N = ncols; p.K = out;
+  p.nz1 = nr.nz1; p.ksplit = 1;
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
-  const int nz = R * nz1;
-  if (rank1_H) {
+  const int nz = R * nr.nz1;
+  if (dy.rank1) {
     if (maskH) return run_gemm<PA_RANK1, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
     return run_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
   }
@@ -227,7 +304,7 @@ int Engine::linear_dgrad(const Mat& dY, int M, const NetRef& nr, int layer, int 
 }
 
 // split-K factor for a weight gradient: enough workgroups to fill 256 CUs, chunk aligned
-static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int max_slab) {
+static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
   const int cfg = pick_cfg(Mout, Nout, Krows);
   int TM, TN, TK;
   switch (cfg) {
@@ -239,43 +316,43 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int max_slab) {
   const int tiles = ((Mout + TM - 1) / TM) * ((Nout + TN - 1) / TN) * nz;
   const int kchunks = (Krows + TK - 1) / TK;
   int ks = (512 + tiles - 1) / tiles;
-  ks = std::max(1, std::min(ks, std::min(max_slab, kchunks)));
-  // at least 2 chunks per split
+  ks = std::max(1, std::min(ks, std::min(cap, kchunks)));
   while (ks > 1 && (kchunks + ks - 1) / ks < 2) --ks;
   return ks;
 }
 
-int Engine::linear_wgrad(const Mat& dY, const Mat& X, int M, const NetRef& nr, int layer, long g_net_off, int ksplit,
-                         int nz1, const char* tag, const Mat* rank1_H, const Mat* rowv) {
+int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
+                         const char* tag, int in_row0, int in_rows) {
   const NetLayout& l = *nr.lay;
+  const int in = l.layer_in(layer), out = l.layer_out(layer);
+  if (in_rows < 0) in_rows = in;
+  if (slab0 + ksplit > max_slab) return fail("wgrad: slab budget exceeded");
   GemmP p;
   memset(&p, 0, sizeof(p));
-  if (rank1_H) {
-    p.A = {rank1_H->p, rank1_H->rs, rank1_H->cs};
-    p.a_sr = 1; p.a_sk = rank1_H->pitch; p.a_trans = 1;
-    p.rowv = {rowv->p, rowv->rs, rowv->cs};
-    p.colv = {nr.base + l.w_off[l.L], nr.rs, nr.cs};
-  } else {
-    p.A = {dY.p, dY.rs, dY.cs};
-    p.a_sr = 1; p.a_sk = dY.pitch;
+  p.A = {dy.m.p, dy.m.rs, dy.m.cs};
+  p.a_sr = 1; p.a_sk = dy.m.pitch;
+  if (dy.rank1) {
+    p.a_trans = 1;
+    p.rowv = {dy.rowv.p, dy.rowv.rs, dy.rowv.cs};
+    p.colv = {nr.base + l.w_off[l.L], nr.rs, l.w_ms[l.L]};
   }
   p.B = {X.p, X.rs, X.cs};
   p.b_sr = 1; p.b_sk = X.pitch;
-  p.ones_row = l.layer_in(layer);
-  p.M = l.layer_out(layer); p.N = l.layer_in(layer) + 1; p.K = M;
-  p.nz1 = nz1; p.ksplit = ksplit;
+  p.ones_row = in_rows;
+  p.M = out; p.N = in_rows + (with_bias ? 1 : 0); p.K = M;
+  p.nz1 = nr.nz1; p.ksplit = ksplit;
   const long g_rs = (long)max_slab * P_train;
-  p.C = grads + g_net_off + l.w_off[layer];
-  p.c_s0 = g_rs; p.c_s1 = nr.cs; p.c_sr = l.layer_in(layer); p.c_ks = P_train;
-  p.bias_out = grads + g_net_off + l.b_off[layer];
-  p.bo_s0 = g_rs; p.bo_s1 = nr.cs; p.bo_ks = P_train;
-  const int nz = R * nz1;
-  if (rank1_H) return run_gemm<PA_RANK1, PB_ONES, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
+  float* g = grads + nr.g_off + (long)slab0 * P_train;
+  if (l.ens) { p.C = g + l.w_off[layer] + (long)in_row0 * out; p.c_sr = 1; p.c_sn = out; }
+  else { p.C = g + l.w_off[layer] + in_row0; p.c_sr = in; p.c_sn = 1; }
+  p.c_s0 = g_rs; p.c_s1 = l.w_ms[layer]; p.c_ks = P_train;
+  if (with_bias) { p.bias_out = g + l.b_off[layer]; p.bo_s0 = g_rs; p.bo_s1 = l.b_ms[layer]; p.bo_ks = P_train; }
+  const int nz = R * nr.nz1;
+  if (dy.rank1) return run_gemm<PA_RANK1, PB_ONES, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
   return run_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
 }
 
-int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, bool polyak,
-                 int target_net, unsigned long long t_div) {
+int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div) {
   AdamP a;
   memset(&a, 0, sizeof(a));
   const NetLayout& l = lay[net];
@@ -283,65 +360,132 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   a.m = adam_m + net_off[net]; a.v = adam_v + net_off[net];
   a.g = grads + net_off[net]; a.g_s0 = (long)max_slab * P_train; a.g_s1 = l.size; a.g_ks = P_train;
   a.nseg = (int)segs.size();
-  if (a.nseg > 8) return fail("too many adam segments");
+  if (a.nseg > 12) return fail("too many adam segments");
   for (int i = 0; i < a.nseg; ++i) { a.seg_end[i] = segs[i].first; a.seg_nslab[i] = segs[i].second; }
-  if (polyak) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.size; }
+  if (target_net >= 0) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.size; }
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
   a.b1 = cfg.adam_beta1; a.b2 = cfg.adam_beta2; a.eps = cfg.adam_eps; a.tau = cfg.tau;
   a.gstep = gstep; a.t_div = t_div;
-  dim3 grid((unsigned)((l.size + 255) / 256), nnets, R);
-  prof_begin("adam", 0);
-  hipLaunchKernelGGL(k_adam, grid, dim3(256), 0, stream, a);
-  prof_end();
-  if (hipGetLastError() != hipSuccess) return fail("adam launch failed");
+  ORL_LAUNCH("adam", k_adam, dim3((unsigned)((l.size + 255) / 256), nnets, R), dim3(256), a);
   return 0;
 }
 
+int Engine::polyak(int target_net, int src_net, int nnets) {
+  const long P = lay[src_net].size;
+  ORL_LAUNCH("polyak", k_polyak, dim3((unsigned)((P + 255) / 256), nnets, R), dim3(256), net_ptr(0, target_net), P_tgt, P,
+             (const float*)net_ptr(0, src_net), P_train, P, P, cfg.tau);
+  return 0;
+}
+
+int Engine::assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep) {
+  AssembleP a;
+  memset(&a, 0, sizeof(a));
+  a.obs = obs.p; a.obs_rs = obs.rs; a.OP = obs.pitch; a.od = od;
+  if (act) { a.act = act->p; a.act_rs = act->rs; a.apitch = act->pitch; }
+  a.ad = ad;
+  a.X = X.p; a.x_rs = X.rs; a.XP = X.pitch; a.row0 = row0; a.rows = rows; a.rep = rep;
+  ORL_LAUNCH("assemble", k_assemble, dim3((rows + 255) / 256, R), dim3(256), a);
+  return 0;
+}
+
+int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag) {
+  const int Ln = nr.lay->L;
+  std::string t = tag;
+  for (int i = 0; i < Ln; ++i)
+    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd").c_str())) return -1;
+  return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
+}
+
+// Adam segment table: one (end offset, slab count) pair per weight tensor and per bias tensor
+static std::vector<std::pair<long, int>> make_segs(const NetLayout& l, const std::vector<int>& ksW, const std::vector<int>& ksB) {
+  std::vector<std::pair<long, int>> s;
+  for (int i = 0; i <= l.L; ++i) {
+    s.push_back({l.b_off[i], ksW[i]});   // weights of layer i end where its bias starts
+    const long bend = l.b_off[i] + (l.ens ? (long)l.members * l.layer_out(i) : l.layer_out(i));
+    s.push_back({bend, ksB[i]});
+  }
+  if (l.extra_off >= 0) s.push_back({l.size, 1});
+  return s;
+}
+
 // generic backward through an MLP family.  dTail: [M x out_dim] gradient w.r.t. the tail output.
-struct BwdOut { std::vector<std::pair<long, int>> segs; };
-static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::vector<Mat>& hs, int M, int nz1,
-                        const Mat& dTail, std::vector<Mat>& dz, bool want_w, long g_net_off, bool want_dx, int dx_col0,
-                        int dx_ncols, const Mat* dX, const char* tag, BwdOut* out) {
+struct BwdOut { std::vector<int> ks; };
+static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::vector<Mat>& hs, int M, const Mat& dTail,
+                        std::vector<Mat>& dz, bool want_w, bool want_dx, int dx_col0, int dx_ncols, const Mat* dX,
+                        const char* tag, BwdOut* out) {
   const NetLayout& l = *nr.lay;
   const int L = l.L;
   const bool rank1 = (l.out_dim == 1);
-  const int nz = e->R * nz1;
+  const int nz = e->R * nr.nz1;
   std::vector<int> ks(L + 1, 1);
   std::string t = tag;
   if (want_w) {
-    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i) + 1, M, nz, e->max_slab);
-    if (e->linear_wgrad(dTail, hs[L - 1], M, nr, L, g_net_off, ks[L], nz1, (t + ".wgrad_tail").c_str())) return -1;
+    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i) + 1, M, nz, e->max_slab / 2);
+    if (e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
   }
-  const Mat* curH = nullptr;   // rank-1 virtual dz
-  Mat cur;
-  if (rank1) curH = &hs[L - 1];
+  DY cur;
+  if (rank1) cur = DY::virt(hs[L - 1], dTail);
   else {
-    if (e->linear_dgrad(dTail, M, nr, L, 0, l.layer_in(L), &hs[L - 1], dz[L - 1], nz1, (t + ".dgrad_tail").c_str())) return -1;
-    cur = dz[L - 1];
+    if (e->linear_dgrad(DY::plain(dTail), M, nr, L, 0, l.layer_in(L), &hs[L - 1], dz[L - 1], (t + ".dgrad_tail").c_str())) return -1;
+    cur = DY::plain(dz[L - 1]);
   }
   for (int i = L - 1; i >= 0; --i) {
     const Mat& xin = (i == 0) ? X : hs[i - 1];
     if (want_w) {
-      if (e->linear_wgrad(cur, xin, M, nr, i, g_net_off, ks[i], nz1, (t + ".wgrad" + std::to_string(i)).c_str(), curH, &dTail)) return -1;
+      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str())) return -1;
     }
     if (i > 0) {
-      if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], nz1, (t + ".dgrad" + std::to_string(i)).c_str(), curH, &dTail)) return -1;
-      cur = dz[i - 1];
-      curH = nullptr;
+      if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], (t + ".dgrad" + std::to_string(i)).c_str())) return -1;
+      cur = DY::plain(dz[i - 1]);
     } else if (want_dx) {
-      if (e->linear_dgrad(cur, M, nr, 0, dx_col0, dx_ncols, nullptr, *dX, nz1, (t + ".dgrad_x").c_str(), curH, &dTail)) return -1;
+      if (e->linear_dgrad(cur, M, nr, 0, dx_col0, dx_ncols, nullptr, *dX, (t + ".dgrad_x").c_str())) return -1;
     }
   }
-  if (out) {
-    out->segs.clear();
-    for (int i = 0; i <= L; ++i) out->segs.push_back({l.b_off[i] + l.layer_out(i), ks[i]});
-  }
+  if (out) out->ks = ks;
   return 0;
 }
 
+// tanh-Gaussian sampling launch (up to 3 jobs)
+static int launch_sample(Engine* e, const Mat& head, int A, const SampleJob* jobs, int njobs) {
+  SampleP sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.head = head.p; sp.head_rs = head.rs; sp.A = A;
+  int maxrows = 0;
+  for (int i = 0; i < njobs; ++i) { sp.job[i] = jobs[i]; maxrows = std::max(maxrows, jobs[i].rows); }
+  e->prof_begin("tanh_sample", 0);
+  hipLaunchKernelGGL(k_tanh_sample, dim3((maxrows + 255) / 256, njobs, e->R), dim3(256), 0, e->stream, sp);
+  e->prof_end();
+  return hipGetLastError() == hipSuccess ? 0 : fail("tanh_sample launch");
+}
+static SampleJob make_job(int head_row0, int rows, int rep, const Mat& eps, const Mat& dst, int dst_col, int dst_row0, const Mat& logp) {
+  SampleJob j;
+  memset(&j, 0, sizeof(j));
+  j.head_row0 = head_row0; j.rows = rows; j.rep = rep; j.eps = eps.p; j.eps_rs = eps.rs;
+  j.dst = dst.p; j.dst_rs = dst.rs; j.dst_pitch = dst.pitch; j.dst_col = dst_col; j.dst_row0 = dst_row0;
+  j.logp = logp.p; j.logp_rs = logp.rs;
+  return j;
+}
+
+}  // namespace orl
+
+#include "algo_cql.inc"
+#include "algo_iql.inc"
+#include "algo_td3bc.inc"
+#include "algo_edac.inc"
+
+namespace orl {
+
 // ---------------------------------------------------------------------------------------------
-// init
+// init / step driver
 // ---------------------------------------------------------------------------------------------
+int Engine::build_common() {
+  // batch slots: obs and next_obs adjacent so [obs; next_obs] is one 2B-row matrix
+  alloc("b_obs2", 2 * B, OP);
+  alloc("b_act", B, AP); alloc("b_rew", B, 1); alloc("b_term", B, 1);
+  alloc("ones", std::max(B, 16), 1);
+  return 0;
+}
+
 int Engine::init(const orl_config& c) {
   cfg = c;
   int ndev = 0;
@@ -354,10 +498,11 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   R = c.n_runs; B = c.batch_size; od = c.obs_dim; ad = c.act_dim;
   N = c.num_repeat_actions > 0 ? c.num_repeat_actions : 1;
-  OP = rup(od, 4); AP = rup(ad, 4); XP = rup(od + ad, 4); L = c.n_hidden; Hlast = c.hidden[L - 1];
+  OP = rup(od, 4); AP = rup(ad, 4); XP = rup(od + ad, 4); L = c.n_hidden;
+  K = (c.algo == ORL_ALGO_EDAC) ? c.num_critics : 2;
   const long arena_floats = (long)R * (P_train + P_tgt);
-  if (c.external_arena) { arena = c.external_arena; arena_owned = false; }
-  else { arena = raw_alloc(sizeof(float) * arena_floats); arena_owned = true; if (!arena) return fail("hipMalloc arena"); }
+  if (c.external_arena) arena = c.external_arena;
+  else { arena = raw_alloc(sizeof(float) * arena_floats); if (!arena) return fail("hipMalloc arena"); }
   adam_m = raw_alloc(sizeof(float) * R * P_train);
   adam_v = raw_alloc(sizeof(float) * R * P_train);
   grads = raw_alloc(sizeof(float) * (size_t)R * max_slab * P_train);
@@ -376,246 +521,68 @@ int Engine::init(const orl_config& c) {
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
-  if (c.algo == ORL_ALGO_CQL) { if (cql_build()) return -1; }
+  if (build_common()) return -1;
+  int rc = -1;
+  switch (c.algo) {
+    case ORL_ALGO_CQL: rc = cql_build(); break;
+    case ORL_ALGO_IQL: rc = iql_build(); break;
+    case ORL_ALGO_TD3BC: rc = td3bc_build(); break;
+    case ORL_ALGO_EDAC: rc = edac_build(); break;
+  }
+  if (rc) return rc;
+  nm = (int)metric_names.size();
+  if (nm > ORL_MAX_METRICS) return fail("too many metrics");
   metrics_last = raw_alloc(sizeof(float) * R * nm);
   metrics_sum = raw_alloc(sizeof(float) * R * nm);
-  d_idx = (long long*)raw_alloc(sizeof(long long) * R * B);
+  {
+    Mat ones = W("ones");
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)((ones.rs * R + 255) / 256)), dim3(256), 0, stream, ones.p, ones.rs * R, 1.0f);
+  }
   ORL_HIP(hipStreamSynchronize(stream));
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------
-// CQL (cql.py:87-207; oracle/cql.py)
-// ---------------------------------------------------------------------------------------------
-int Engine::cql_build() {
-  const int A = ad, BN = B * N, Mc = B + 3 * BN, Bt = cfg.max_q_backup ? BN : B;
-  metric_names = {"loss/actor", "loss/critic1", "loss/critic2"};
-  if (cfg.auto_alpha) { metric_names.push_back("loss/alpha"); metric_names.push_back("alpha"); }
-  if (cfg.with_lagrange) { metric_names.push_back("loss/cql_alpha"); metric_names.push_back("cql_alpha"); }
-  nm = (int)metric_names.size();
-  // batch slots: obs and next_obs adjacent so [obs; next_obs] is one 2B-row matrix
-  alloc("b_obs2", 2 * B, OP);
-  alloc("b_act", B, AP); alloc("b_rew", B, 1); alloc("b_term", B, 1);
-  alloc("n_eps_actor", B, A); alloc("n_eps_next", Bt, A); alloc("n_urand", BN, A);
-  alloc("n_eps_pi", BN, A); alloc("n_eps_npi", BN, A);
-  for (int i = 0; i < L; ++i) {
-    const int h = cfg.hidden[i];
-    alloc("ah" + std::to_string(i), B, h);
-    alloc("dah" + std::to_string(i), B, h);
-    alloc("ah2_" + std::to_string(i), 2 * B, h);
-    alloc("ca" + std::to_string(i), B, h, 2);
-    alloc("dca" + std::to_string(i), B, h, 2);
-    alloc("ct" + std::to_string(i), Bt, h, 2);
-    alloc("ch" + std::to_string(i), Mc, h, 2);
-    if (i < L - 1) alloc("dch" + std::to_string(i), Mc, h, 2);
-  }
-  alloc("head", B, 2 * A); alloc("head2", 2 * B, 2 * A); alloc("dhead", B, 2 * A);
-  alloc("xa", B, XP); alloc("xt", Bt, XP); alloc("xc", Mc, XP);
-  alloc("logp_a", B, 1); alloc("logp_next", Bt, 1); alloc("logp_pi", BN, 1); alloc("logp_npi", BN, 1);
-  alloc("qa", B, 1, 2); alloc("dqa", B, 1, 2); alloc("dxa", B, A, 2);
-  alloc("qt", Bt, 1, 2); alloc("q", Mc, 1, 2); alloc("dq", Mc, 1, 2); alloc("target_q", B, 1);
-  taps["q1"] = {ws["q"].net(0), B, 1};
-  taps["q2"] = {ws["q"].net(1), B, 1};
-  taps["q1_all"] = {ws["q"].net(0), Mc, 1};
-  taps["q2_all"] = {ws["q"].net(1), Mc, 1};
-  taps["q1a"] = {ws["qa"].net(0), B, 1};
-  taps["q2a"] = {ws["qa"].net(1), B, 1};
-  taps["logp_a"] = {ws["logp_a"], B, 1};
-  taps["target_q"] = {ws["target_q"], B, 1};
-  taps["xc"] = {ws["xc"], Mc, XP};
-  taps["dq1"] = {ws["dq"].net(0), Mc, 1};
-  return 0;
-}
-
-static int launch_assemble(Engine* e, const Mat& obs, int OP, int od, const Mat* act, int ad, const Mat& X, int XP, int row0, int rows, int rep) {
-  AssembleP a;
-  memset(&a, 0, sizeof(a));
-  a.obs = obs.p; a.obs_rs = obs.rs; a.OP = OP; a.od = od;
-  if (act) { a.act = act->p; a.act_rs = act->rs; a.apitch = act->pitch; }
-  a.ad = ad;
-  a.X = X.p; a.x_rs = X.rs; a.XP = XP; a.row0 = row0; a.rows = rows; a.rep = rep;
-  e->prof_begin("assemble", 0);
-  hipLaunchKernelGGL(k_assemble, dim3((rows + 255) / 256, e->R), dim3(256), 0, e->stream, a);
-  e->prof_end();
-  return hipGetLastError() == hipSuccess ? 0 : fail("assemble launch");
-}
-
-int Engine::cql_step() {
-  const int A = ad, BN = B * N, Mc = B + 3 * BN, Bt = cfg.max_q_backup ? BN : B;
-  auto W = [&](const std::string& n) -> Mat& { return ws[n]; };
-  const NetRef actor = net_ref(ORL_NET_ACTOR), crit = net_ref(ORL_NET_CRITIC1), tgt = net_ref(ORL_NET_CRITIC1_OLD);
-  Mat obs = W("b_obs2"), nobs = W("b_obs2").rows(B), obs2 = W("b_obs2");
-  std::vector<Mat> ah, dah, ah2, ca, dca, ct, ch, dch;
-  for (int i = 0; i < L; ++i) {
-    const std::string s = std::to_string(i);
-    ah.push_back(W("ah" + s)); dah.push_back(W("dah" + s)); ah2.push_back(W("ah2_" + s));
-    ca.push_back(W("ca" + s)); dca.push_back(W("dca" + s)); ct.push_back(W("ct" + s)); ch.push_back(W("ch" + s));
-    if (i < L - 1) dch.push_back(W("dch" + s)); else dch.push_back(Mat());
-  }
-  Mat xa = W("xa"), xt = W("xt"), xc = W("xc");
-  xa.cs = 0; xt.cs = 0; xc.cs = 0;   // shared by both critics
-
-  // ---------------- phase A: actor update (cql.py:92-106) ----------------
-  for (int i = 0; i < L; ++i)
-    if (linear_fwd(i == 0 ? obs : ah[i - 1], B, actor, i, ah[i], true, 1, "actor.fwd")) return -1;
-  if (linear_fwd(ah[L - 1], B, actor, L, W("head"), false, 1, "actor.head")) return -1;
-  if (launch_assemble(this, obs, OP, od, nullptr, ad, xa, XP, 0, B, 1)) return -1;
-  {
-    SampleP sp; memset(&sp, 0, sizeof(sp));
-    sp.head = W("head").p; sp.head_rs = W("head").rs; sp.A = A;
-    SampleJob& j = sp.job[0];
-    j.head_row0 = 0; j.rows = B; j.rep = 1; j.eps = W("n_eps_actor").p; j.eps_rs = W("n_eps_actor").rs;
-    j.dst = xa.p; j.dst_rs = xa.rs; j.dst_pitch = XP; j.dst_col = od; j.dst_row0 = 0;
-    j.logp = W("logp_a").p; j.logp_rs = W("logp_a").rs;
-    prof_begin("tanh_sample", 0);
-    hipLaunchKernelGGL(k_tanh_sample, dim3((B + 255) / 256, 1, R), dim3(256), 0, stream, sp);
-    prof_end();
-  }
-  for (int i = 0; i < L; ++i)
-    if (linear_fwd(i == 0 ? xa : ca[i - 1], B, crit, i, ca[i], true, 2, "critic.fwd_a")) return -1;
-  if (linear_fwd(ca[L - 1], B, crit, L, W("qa"), false, 2, "critic.head_a")) return -1;
-  {
-    ActorLossP p; memset(&p, 0, sizeof(p));
-    p.qa = W("qa").p; p.qa_rs = W("qa").rs; p.qa_cs = W("qa").cs; p.dqa = W("dqa").p;
-    p.logp = W("logp_a").p; p.logp_rs = W("logp_a").rs; p.B = B; p.K = 2;
-    p.sc = scalars; p.hy = hyper; p.auto_alpha = cfg.auto_alpha; p.fixed_alpha = cfg.alpha;
-    p.target_entropy = cfg.target_entropy; p.clamp_alpha01 = 0;
-    p.b1 = cfg.adam_beta1; p.b2 = cfg.adam_beta2; p.eps = cfg.adam_eps; p.gstep = gstep;
-    p.metrics_last = metrics_last; p.metrics_sum = metrics_sum; p.nm = nm;
-    p.m_actor = 0; p.m_alpha_loss = 3; p.m_alpha = 4;
-    prof_begin("actor_loss", 0);
-    hipLaunchKernelGGL(k_actor_loss, dim3(R), dim3(256), 0, stream, p);
-    prof_end();
-  }
-  {
-    Mat dxa = W("dxa");
-    if (mlp_backward(this, crit, xa, ca, B, 2, W("dqa"), dca, false, 0, true, od, A, &dxa, "critic.bwd_a", nullptr)) return -1;
-  }
-  {
-    HeadBwdP p; memset(&p, 0, sizeof(p));
-    p.dxa = W("dxa").p; p.dxa_rs = W("dxa").rs; p.dxa_cs = W("dxa").cs; p.dxa_pitch = A; p.K = 2;
-    p.head = W("head").p; p.head_rs = W("head").rs; p.eps = W("n_eps_actor").p; p.eps_rs = W("n_eps_actor").rs;
-    p.xa = xa.p; p.xa_rs = xa.rs; p.XP = XP; p.od = od; p.dhead = W("dhead").p; p.dhead_rs = W("dhead").rs;
-    p.sc = scalars; p.auto_alpha = cfg.auto_alpha; p.fixed_alpha = cfg.alpha; p.B = B; p.A = A;
-    prof_begin("head_bwd", 0);
-    hipLaunchKernelGGL(k_head_bwd, dim3((B + 255) / 256, R), dim3(256), 0, stream, p);
-    prof_end();
-  }
-  BwdOut bo;
-  if (mlp_backward(this, actor, obs, ah, B, 1, W("dhead"), dah, true, net_off[ORL_NET_ACTOR], false, 0, 0, nullptr, "actor.bwd", &bo)) return -1;
-  if (adam(ORL_NET_ACTOR, 1, ORL_OPT_ACTOR, bo.segs, false, -1)) return -1;
-
-  // ---------------- phase T: targets + repeated-action sampling with the UPDATED actor ----------------
-  for (int i = 0; i < L; ++i)
-    if (linear_fwd(i == 0 ? obs2 : ah2[i - 1], 2 * B, actor, i, ah2[i], true, 1, "actor.fwd2")) return -1;
-  if (linear_fwd(ah2[L - 1], 2 * B, actor, L, W("head2"), false, 1, "actor.head2")) return -1;
-  // critic input rows: [0,B) (obs, a_data) ; [B,B+BN) (obs rep, a_pi) ; next BN (obs rep, a_next_pi) ; last BN (obs rep, u_rand)
-  {
-    Mat act = W("b_act");
-    if (launch_assemble(this, obs, OP, od, &act, ad, xc, XP, 0, B, 1)) return -1;
-    if (launch_assemble(this, obs, OP, od, nullptr, ad, xc, XP, B, BN, N)) return -1;
-    if (launch_assemble(this, obs, OP, od, nullptr, ad, xc, XP, B + BN, BN, N)) return -1;
-    Mat ur = W("n_urand");
-    if (launch_assemble(this, obs, OP, od, &ur, ad, xc, XP, B + 2 * BN, BN, N)) return -1;
-    if (launch_assemble(this, nobs, OP, od, nullptr, ad, xt, XP, 0, Bt, cfg.max_q_backup ? N : 1)) return -1;
-  }
-  {
-    SampleP sp; memset(&sp, 0, sizeof(sp));
-    sp.head = W("head2").p; sp.head_rs = W("head2").rs; sp.A = A;
-    SampleJob& j0 = sp.job[0];   // next actions for the TD target (cql.py:108-130)
-    j0.head_row0 = B; j0.rows = Bt; j0.rep = cfg.max_q_backup ? N : 1; j0.eps = W("n_eps_next").p; j0.eps_rs = W("n_eps_next").rs;
-    j0.dst = xt.p; j0.dst_rs = xt.rs; j0.dst_pitch = XP; j0.dst_col = od; j0.dst_row0 = 0;
-    j0.logp = W("logp_next").p; j0.logp_rs = W("logp_next").rs;
-    SampleJob& j1 = sp.job[1];   // a ~ pi(tmp_obss)  (cql.py:149)
-    j1.head_row0 = 0; j1.rows = BN; j1.rep = N; j1.eps = W("n_eps_pi").p; j1.eps_rs = W("n_eps_pi").rs;
-    j1.dst = xc.p; j1.dst_rs = xc.rs; j1.dst_pitch = XP; j1.dst_col = od; j1.dst_row0 = B;
-    j1.logp = W("logp_pi").p; j1.logp_rs = W("logp_pi").rs;
-    SampleJob& j2 = sp.job[2];   // a ~ pi(tmp_next_obss), evaluated at tmp_obss (cql.py:150)
-    j2.head_row0 = B; j2.rows = BN; j2.rep = N; j2.eps = W("n_eps_npi").p; j2.eps_rs = W("n_eps_npi").rs;
-    j2.dst = xc.p; j2.dst_rs = xc.rs; j2.dst_pitch = XP; j2.dst_col = od; j2.dst_row0 = B + BN;
-    j2.logp = W("logp_npi").p; j2.logp_rs = W("logp_npi").rs;
-    prof_begin("tanh_sample", 0);
-    hipLaunchKernelGGL(k_tanh_sample, dim3((BN + 255) / 256, 3, R), dim3(256), 0, stream, sp);
-    prof_end();
-  }
-  for (int i = 0; i < L; ++i)
-    if (linear_fwd(i == 0 ? xt : ct[i - 1], Bt, tgt, i, ct[i], true, 2, "target.fwd")) return -1;
-  if (linear_fwd(ct[L - 1], Bt, tgt, L, W("qt"), false, 2, "target.head")) return -1;
-
-  // ---------------- phase C: critics (cql.py:132-190) ----------------
-  for (int i = 0; i < L; ++i)
-    if (linear_fwd(i == 0 ? xc : ch[i - 1], Mc, crit, i, ch[i], true, 2, "critic.fwd")) return -1;
-  if (linear_fwd(ch[L - 1], Mc, crit, L, W("q"), false, 2, "critic.head")) return -1;
-  {
-    CqlLossP p; memset(&p, 0, sizeof(p));
-    p.q = W("q").p; p.q_rs = W("q").rs; p.q_cs = W("q").cs; p.dq = W("dq").p;
-    p.qt = W("qt").p; p.qt_rs = W("qt").rs; p.qt_cs = W("qt").cs;
-    p.rew = W("b_rew").p; p.term = W("b_term").p; p.bt_rs = W("b_rew").rs;
-    p.logp_next = W("logp_next").p; p.lpn_rs = W("logp_next").rs;
-    p.logp_pi = W("logp_pi").p; p.logp_npi = W("logp_npi").p; p.lpp_rs = W("logp_pi").rs;
-    p.target_q = W("target_q").p; p.tq_rs = W("target_q").rs;
-    p.B = B; p.N = N; p.A = A; p.gamma = cfg.gamma; p.w = cfg.cql_weight; p.T = cfg.temperature; p.thr = cfg.lagrange_threshold;
-    p.max_q_backup = cfg.max_q_backup; p.det_backup = cfg.deterministic_backup; p.with_lagrange = cfg.with_lagrange;
-    p.auto_alpha = cfg.auto_alpha; p.fixed_alpha = cfg.alpha;
-    p.sc = scalars; p.hy = hyper; p.b1 = cfg.adam_beta1; p.b2 = cfg.adam_beta2; p.eps = cfg.adam_eps; p.gstep = gstep;
-    p.metrics_last = metrics_last; p.metrics_sum = metrics_sum; p.nm = nm;
-    p.m_c1 = 1; p.m_c2 = 2; p.m_cqla_loss = cfg.auto_alpha ? 5 : 3; p.m_cqla = cfg.auto_alpha ? 6 : 4;
-    prof_begin("cql_loss", 0);
-    hipLaunchKernelGGL(k_cql_loss, dim3(R), dim3(256), 0, stream, p);
-    prof_end();
-  }
-  BwdOut bc;
-  if (mlp_backward(this, crit, xc, ch, Mc, 2, W("dq"), dch, true, net_off[ORL_NET_CRITIC1], false, 0, 0, nullptr, "critic.bwd", &bc)) return -1;
-  if (adam(ORL_NET_CRITIC1, 2, ORL_OPT_CRITIC, bc.segs, true, ORL_NET_CRITIC1_OLD)) return -1;
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// sampling / noise / step driver
-// ---------------------------------------------------------------------------------------------
-int Engine::enqueue_sample(const long long* idx_dev) {
-  if (!d_obs) return fail("no dataset loaded (orl_buffer_load)");
-  GatherP g; memset(&g, 0, sizeof(g));
-  g.obs = d_obs; g.nobs = d_nobs; g.act = d_act; g.rew = d_rew; g.term = d_term; g.n = n_data;
-  g.OP = OP; g.AP = AP; g.od = od; g.ad = ad; g.B = B; g.idx = idx_dev;
-  Mat o2 = ws["b_obs2"];
-  g.b_obs = o2.p; g.b_nobs = o2.p + (long)B * OP;
-  g.b_act = ws["b_act"].p; g.b_rew = ws["b_rew"].p; g.b_term = ws["b_term"].p;
+int Engine::enqueue_sample() {
+  if (!buf || !buf->obs) return fail("no replay buffer attached (orl_engine_attach_buffer)");
+  GatherP g;
+  memset(&g, 0, sizeof(g));
+  g.obs = buf->obs; g.nobs = buf->nobs; g.act = buf->act; g.rew = buf->rew; g.term = buf->term; g.n = buf->n;
+  g.OP = buf->OP; g.AP = buf->AP; g.od = od; g.ad = ad; g.B = B; g.W = std::max(OP, AP);
+  Mat o2 = W("b_obs2");
+  g.b_obs = o2.p; g.b_nobs = o2.p + (long)B * OP; g.obs_rs = o2.rs; g.nobs_rs = o2.rs; g.d_op = OP;
+  g.b_act = W("b_act").p; g.act_rs = W("b_act").rs; g.d_ap = AP;
+  g.b_rew = W("b_rew").p; g.rew_rs = W("b_rew").rs; g.b_term = W("b_term").p; g.term_rs = W("b_term").rs;
   g.seed = cfg.seed; g.gstep = gstep;
-  // batch slot run strides: b_obs2 has 2B rows per run -> the kernel indexes dst = r*B+row, so launch per run
-  // with explicit run offsets instead (keeps the gather kernel simple)
-  for (int r = 0; r < R; ++r) {
-    GatherP gr = g;
-    gr.b_obs = o2.p + r * o2.rs; gr.b_nobs = gr.b_obs + (long)B * OP;
-    gr.b_act = ws["b_act"].p + r * ws["b_act"].rs; gr.b_rew = ws["b_rew"].p + r * ws["b_rew"].rs;
-    gr.b_term = ws["b_term"].p + r * ws["b_term"].rs;
-    gr.idx = idx_dev ? idx_dev + (long)r * B : nullptr;
-    gr.seed = cfg.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1);
-    prof_begin("gather", 0);
-    hipLaunchKernelGGL(k_gather, dim3((B + 63) / 64, 1), dim3(256), 0, stream, gr);
-    prof_end();
-  }
-  return hipGetLastError() == hipSuccess ? 0 : fail("gather launch");
+  ORL_LAUNCH("gather", k_gather, dim3((unsigned)(((long)B * g.W + 255) / 256), R), dim3(256), g);
+  return 0;
 }
 
 int Engine::enqueue_noise() {
-  if (cfg.algo != ORL_ALGO_CQL) return fail("noise: algorithm not built");
-  struct { const char* name; int kind; } slots[] = {{"n_eps_actor", 0}, {"n_eps_next", 0}, {"n_urand", 1}, {"n_eps_pi", 0}, {"n_eps_npi", 0}};
   uint32_t sid = 1;
-  for (auto& s : slots) {
-    const long n = ws_len[s.name];
-    prof_begin("noise", 0);
-    hipLaunchKernelGGL(k_noise, dim3((unsigned)((n / 4 + 256) / 256), R), dim3(256), 0, stream, ws[s.name].p, n, s.kind,
-                       cfg.act_low, cfg.act_high, cfg.seed, gstep, sid++);
-    prof_end();
+  for (auto& s : noise_slots) {
+    const long n = ws_len.at(s.name);
+    ORL_LAUNCH("noise", k_noise, dim3((unsigned)((n / 4 + 256) / 256), R), dim3(256), W(s.name).p, n, s.kind, cfg.act_low,
+               cfg.act_high, cfg.seed, (const unsigned long long*)gstep, sid);
+    ++sid;
   }
-  return hipGetLastError() == hipSuccess ? 0 : fail("noise launch");
+  return 0;
 }
 
-int Engine::enqueue_step() {
+int Engine::n_variants() const { return cfg.algo == ORL_ALGO_TD3BC ? 2 : 1; }
+int Engine::step_variant() const {
+  if (cfg.algo != ORL_ALGO_TD3BC) return 0;
+  const int f = cfg.update_actor_freq > 0 ? cfg.update_actor_freq : 1;
+  return (step_host % f == 0) ? 1 : 0;   // 1 = actor + target-sync step (td3bc.py:107)
+}
+
+int Engine::enqueue_step(int variant) {
   int rc = -1;
-  if (cfg.algo == ORL_ALGO_CQL) rc = cql_step();
-  else return fail("algorithm not built");
+  switch (cfg.algo) {
+    case ORL_ALGO_CQL: rc = cql_step(); break;
+    case ORL_ALGO_IQL: rc = iql_step(); break;
+    case ORL_ALGO_TD3BC: rc = td3bc_step(variant == 1); break;
+    case ORL_ALGO_EDAC: rc = edac_step(); break;
+  }
   if (rc) return rc;
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, stream, gstep);
   return hipGetLastError() == hipSuccess ? 0 : fail("tick launch");
@@ -631,11 +598,14 @@ using namespace orl;
 struct orl_engine {
   Engine e;
 };
+struct orl_buffer {
+  Buffer b;
+};
 
 extern "C" {
 
 const char* orl_last_error(void) { return g_err.c_str(); }
-const char* orl_version(void) { return "orl-engine 0.1 (gfx950, fp32 MFMA)"; }
+const char* orl_version(void) { return "orl-engine 0.2 (gfx950, fp32 MFMA; CQL IQL TD3BC EDAC)"; }
 
 void orl_config_default(orl_config* c, int32_t algo) {
   memset(c, 0, sizeof(*c));
@@ -695,6 +665,7 @@ float* orl_net_ptr(orl_engine* h, int run, int net) {
 int orl_net_set(orl_engine* h, int run, int net, const float* host, int64_t n) {
   float* d = orl_net_ptr(h, run, net);
   if (!d || n != h->e.lay[net].size) return fail("orl_net_set: bad net/run/size");
+  ORL_HIP(hipSetDevice(h->e.dev));
   ORL_HIP(hipMemcpyAsync(d, host, sizeof(float) * n, hipMemcpyHostToDevice, h->e.stream));
   ORL_HIP(hipStreamSynchronize(h->e.stream));
   return 0;
@@ -702,6 +673,7 @@ int orl_net_set(orl_engine* h, int run, int net, const float* host, int64_t n) {
 int orl_net_get(orl_engine* h, int run, int net, float* host, int64_t n) {
   float* d = orl_net_ptr(h, run, net);
   if (!d || n != h->e.lay[net].size) return fail("orl_net_get: bad net/run/size");
+  ORL_HIP(hipSetDevice(h->e.dev));
   ORL_HIP(hipStreamSynchronize(h->e.stream));
   ORL_HIP(hipMemcpy(host, d, sizeof(float) * n, hipMemcpyDeviceToHost));
   return 0;
@@ -712,7 +684,7 @@ int orl_scalar_set(orl_engine* h, int run, int which, float v) {
   RunScalars s;
   ORL_HIP(hipStreamSynchronize(e.stream));
   ORL_HIP(hipMemcpy(&s, e.scalars + run, sizeof(s), hipMemcpyDeviceToHost));
-  if (which == ORL_SCALAR_LOG_ALPHA) { s.log_alpha = v; if (e.cfg.auto_alpha) { s.alpha = expf(v); if (e.cfg.algo == ORL_ALGO_EDAC) s.alpha = fminf(fmaxf(s.alpha, 0.f), 1.f); } }
+  if (which == ORL_SCALAR_LOG_ALPHA) { s.log_alpha = v; if (e.cfg.auto_alpha) s.alpha = expf(v); }   // sac.py:46 / edac.py:45
   else if (which == ORL_SCALAR_CQL_LOG_ALPHA) s.cql_log_alpha = v;
   else return fail("scalar not settable");
   ORL_HIP(hipMemcpy(e.scalars + run, &s, sizeof(s), hipMemcpyHostToDevice));
@@ -748,45 +720,111 @@ int orl_reset_optimizers(orl_engine* h) {
 }
 
 // ---- replay buffer ----
-static int upload_padded(Engine& e, float** dst, const float* src, long n, int dim, int pitch) {
-  *dst = e.raw_alloc(sizeof(float) * n * pitch);
-  if (!*dst) return fail("hipMalloc dataset");
-  ORL_HIP(hipMemcpy2DAsync(*dst, sizeof(float) * pitch, src, sizeof(float) * dim, sizeof(float) * dim, n, hipMemcpyHostToDevice, e.stream));
+int orl_buffer_create(int32_t obs_dim, int32_t act_dim, int32_t device, orl_buffer** out) {
+  if (!out || obs_dim < 1 || act_dim < 1) return fail("orl_buffer_create: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available: the replay buffer lives in MI355X HBM");
+  if (device < 0 || device >= ndev) return fail("bad device ordinal");
+  orl_buffer* h = new orl_buffer();
+  h->b.dev = device; h->b.od = obs_dim; h->b.ad = act_dim; h->b.OP = rup(obs_dim, 4); h->b.AP = rup(act_dim, 4);
+  *out = h;
   return 0;
 }
-int orl_buffer_load(orl_engine* h, const float* obs, const float* act, const float* next_obs, const float* rew, const float* term, int64_t n) {
-  Engine& e = h->e;
+void orl_buffer_destroy(orl_buffer* h) { delete h; }
+static int upload_padded(float** dst, const float* src, long n, int dim, int pitch) {
+  ORL_HIP(hipMalloc((void**)dst, sizeof(float) * n * pitch));
+  ORL_HIP(hipMemset(*dst, 0, sizeof(float) * n * pitch));
+  ORL_HIP(hipMemcpy2D(*dst, sizeof(float) * pitch, src, sizeof(float) * dim, sizeof(float) * dim, n, hipMemcpyHostToDevice));
+  return 0;
+}
+int orl_buffer_load(orl_buffer* h, const float* obs, const float* act, const float* next_obs, const float* rew, const float* term, int64_t n) {
+  Buffer& b = h->b;
   if (n <= 0) return fail("empty dataset");
-  if (e.d_obs) return fail("dataset already loaded");
-  if (upload_padded(e, &e.d_obs, obs, n, e.od, e.OP)) return -1;
-  if (upload_padded(e, &e.d_nobs, next_obs, n, e.od, e.OP)) return -1;
-  if (upload_padded(e, &e.d_act, act, n, e.ad, e.AP)) return -1;
-  if (upload_padded(e, &e.d_rew, rew, n, 1, 1)) return -1;
-  if (upload_padded(e, &e.d_term, term, n, 1, 1)) return -1;
-  e.n_data = n;
-  ORL_HIP(hipStreamSynchronize(e.stream));
+  ORL_HIP(hipSetDevice(b.dev));
+  for (float** p : {&b.obs, &b.nobs, &b.act, &b.rew, &b.term}) if (*p) { hipFree(*p); *p = nullptr; }
+  if (upload_padded(&b.obs, obs, n, b.od, b.OP)) return -1;
+  if (upload_padded(&b.nobs, next_obs, n, b.od, b.OP)) return -1;
+  if (upload_padded(&b.act, act, n, b.ad, b.AP)) return -1;
+  if (upload_padded(&b.rew, rew, n, 1, 1)) return -1;
+  if (upload_padded(&b.term, term, n, 1, 1)) return -1;
+  b.n = n;
   return 0;
 }
-int64_t orl_buffer_size(orl_engine* h) { return h->e.n_data; }
-int orl_buffer_normalize_obs(orl_engine*, float, float*, float*) { return fail("normalize_obs: not built yet"); }
-int orl_buffer_sample(orl_engine* h, const int64_t* idx, orl_batch* out) {
-  Engine& e = h->e;
-  if (idx) {
-    for (long i = 0; i < (long)e.R * e.B; ++i) if (idx[i] < 0 || idx[i] >= e.n_data) return fail("sample index out of range");
-    ORL_HIP(hipMemcpyAsync(e.d_idx, idx, sizeof(long long) * e.R * e.B, hipMemcpyHostToDevice, e.stream));
+int64_t orl_buffer_size(orl_buffer* h) { return h->b.n; }
+int orl_buffer_normalize_obs(orl_buffer* h, float eps, float* mean_out, float* std_out) {
+  Buffer& b = h->b;
+  if (!b.obs) return fail("normalize_obs: empty buffer");
+  ORL_HIP(hipSetDevice(b.dev));
+  double* sums = nullptr;
+  ORL_HIP(hipMalloc((void**)&sums, sizeof(double) * 2 * b.od));
+  ORL_HIP(hipMemset(sums, 0, sizeof(double) * 2 * b.od));
+  hipLaunchKernelGGL(k_colstats, dim3(128, b.od), dim3(256), 0, 0, (const float*)b.obs, b.n, b.OP, b.od, sums);
+  std::vector<double> hs(2 * b.od);
+  ORL_HIP(hipMemcpy(hs.data(), sums, sizeof(double) * 2 * b.od, hipMemcpyDeviceToHost));
+  hipFree(sums);
+  std::vector<float> mean(b.od), sd(b.od);
+  for (int c = 0; c < b.od; ++c) {
+    const double m = hs[c] / (double)b.n;
+    double var = hs[b.od + c] / (double)b.n - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    sd[c] = (float)sqrt(var) + eps;        // buffer.py:90: std + eps
   }
-  if (e.enqueue_sample(idx ? e.d_idx : nullptr)) return -1;
-  ORL_HIP(hipStreamSynchronize(e.stream));
-  if (out) {
-    out->observations = e.ws["b_obs2"].p; out->next_observations = e.ws["b_obs2"].p + (long)e.B * e.OP;
-    out->actions = e.ws["b_act"].p; out->rewards = e.ws["b_rew"].p; out->terminals = e.ws["b_term"].p; out->on_device = 1;
+  float *dm = nullptr, *ds = nullptr;
+  ORL_HIP(hipMalloc((void**)&dm, sizeof(float) * b.od));
+  ORL_HIP(hipMalloc((void**)&ds, sizeof(float) * b.od));
+  ORL_HIP(hipMemcpy(dm, mean.data(), sizeof(float) * b.od, hipMemcpyHostToDevice));
+  ORL_HIP(hipMemcpy(ds, sd.data(), sizeof(float) * b.od, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_normalize, dim3((unsigned)((b.n * b.od + 255) / 256)), dim3(256), 0, 0, b.obs, b.nobs, b.n, b.OP, b.od,
+                     (const float*)dm, (const float*)ds);
+  ORL_HIP(hipDeviceSynchronize());
+  hipFree(dm); hipFree(ds);
+  if (mean_out) memcpy(mean_out, mean.data(), sizeof(float) * b.od);
+  if (std_out) memcpy(std_out, sd.data(), sizeof(float) * b.od);
+  return 0;
+}
+int orl_buffer_sample(orl_buffer* h, const int64_t* idx, int32_t batch, uint64_t seed, float* obs_out, float* act_out,
+                      float* next_obs_out, float* rew_out, float* term_out) {
+  Buffer& b = h->b;
+  if (!b.obs) return fail("sample: empty buffer");
+  if (batch < 1 || !obs_out || !act_out || !next_obs_out || !rew_out || !term_out) return fail("sample: bad arguments");
+  ORL_HIP(hipSetDevice(b.dev));
+  if (idx) {
+    for (int i = 0; i < batch; ++i) if (idx[i] < 0 || idx[i] >= b.n) return fail("sample index out of range");
+    if (b.idx_cap < batch) {
+      if (b.idx) hipFree(b.idx);
+      ORL_HIP(hipMalloc((void**)&b.idx, sizeof(long long) * batch));
+      b.idx_cap = batch;
+    }
+    ORL_HIP(hipMemcpy(b.idx, idx, sizeof(long long) * batch, hipMemcpyHostToDevice));
+  }
+  GatherP g;
+  memset(&g, 0, sizeof(g));
+  g.obs = b.obs; g.nobs = b.nobs; g.act = b.act; g.rew = b.rew; g.term = b.term; g.n = b.n;
+  g.OP = b.OP; g.AP = b.AP; g.od = b.od; g.ad = b.ad; g.B = batch; g.W = std::max(b.od, b.ad);
+  g.idx = idx ? b.idx : nullptr; g.idx_rs = batch;
+  g.b_obs = obs_out; g.b_nobs = next_obs_out; g.b_act = act_out; g.b_rew = rew_out; g.b_term = term_out;
+  g.d_op = b.od; g.d_ap = b.ad;
+  g.seed = seed; g.gstep = nullptr; g.counter = b.counter++;
+  hipLaunchKernelGGL(k_gather, dim3((unsigned)(((long)batch * g.W + 255) / 256), 1), dim3(256), 0, 0, g);
+  ORL_HIP(hipGetLastError());
+  ORL_HIP(hipStreamSynchronize(0));
+  return 0;
+}
+int orl_engine_attach_buffer(orl_engine* h, orl_buffer* b) {
+  if (!b) { h->e.buf = nullptr; return 0; }
+  if (b->b.od != h->e.od || b->b.ad != h->e.ad) return fail("attach_buffer: obs/act dims differ from the engine's");
+  if (b->b.dev != h->e.dev) return fail("attach_buffer: buffer lives on another device");
+  h->e.buf = &b->b;
+  for (int i = 0; i < 2; ++i) {   // captured graphs hold the old dataset pointers
+    if (h->e.graph_exec[i]) { hipGraphExecDestroy(h->e.graph_exec[i]); h->e.graph_exec[i] = nullptr; }
+    if (h->e.graph[i]) { hipGraphDestroy(h->e.graph[i]); h->e.graph[i] = nullptr; }
   }
   return 0;
 }
 
 // ---- hot path ----
 static int copy_rows(Engine& e, const Mat& dst, const float* src, int rows, int dim, bool on_device, long row0 = 0) {
-  // src: [R][rows][dim] packed; dst: per-run padded rows
   if (!src) return fail("null input array");
   for (int r = 0; r < e.R; ++r) {
     ORL_HIP(hipMemcpy2DAsync(dst.p + r * dst.rs + row0 * dst.pitch, sizeof(float) * dst.pitch, src + (long)r * rows * dim,
@@ -798,28 +836,23 @@ static int copy_rows(Engine& e, const Mat& dst, const float* src, int rows, int 
 int orl_step(orl_engine* h, const orl_batch* b, const orl_noise* nz, float* metrics) {
   Engine& e = h->e;
   ORL_HIP(hipSetDevice(e.dev));
-  const int B = e.B, A = e.ad, BN = e.B * e.N, Bt = e.cfg.max_q_backup ? BN : B;
+  const int B = e.B;
   if (b) {
     const bool dv = b->on_device != 0;
-    if (copy_rows(e, e.ws["b_obs2"], b->observations, B, e.od, dv, 0)) return -1;
-    if (copy_rows(e, e.ws["b_obs2"], b->next_observations, B, e.od, dv, B)) return -1;
-    if (copy_rows(e, e.ws["b_act"], b->actions, B, e.ad, dv)) return -1;
-    if (copy_rows(e, e.ws["b_rew"], b->rewards, B, 1, dv)) return -1;
-    if (copy_rows(e, e.ws["b_term"], b->terminals, B, 1, dv)) return -1;
+    if (copy_rows(e, e.W("b_obs2"), b->observations, B, e.od, dv, 0)) return -1;
+    if (copy_rows(e, e.W("b_obs2"), b->next_observations, B, e.od, dv, B)) return -1;
+    if (copy_rows(e, e.W("b_act"), b->actions, B, e.ad, dv)) return -1;
+    if (copy_rows(e, e.W("b_rew"), b->rewards, B, 1, dv)) return -1;
+    if (copy_rows(e, e.W("b_term"), b->terminals, B, 1, dv)) return -1;
   }
   if (nz) {
     const bool dv = nz->on_device != 0;
-    if (e.cfg.algo == ORL_ALGO_CQL) {
-      if (copy_rows(e, e.ws["n_eps_actor"], nz->slot[0], B, A, dv)) return -1;
-      if (copy_rows(e, e.ws["n_eps_next"], nz->slot[1], Bt, A, dv)) return -1;
-      if (copy_rows(e, e.ws["n_urand"], nz->slot[2], BN, A, dv)) return -1;
-      if (copy_rows(e, e.ws["n_eps_pi"], nz->slot[3], BN, A, dv)) return -1;
-      if (copy_rows(e, e.ws["n_eps_npi"], nz->slot[4], BN, A, dv)) return -1;
-    }
+    for (size_t i = 0; i < e.noise_slots.size(); ++i)
+      if (copy_rows(e, e.W(e.noise_slots[i].name), nz->slot[i], e.noise_slots[i].rows, e.ad, dv)) return -1;
   } else {
     if (e.enqueue_noise()) return -1;
   }
-  if (e.enqueue_step()) return -1;
+  if (e.enqueue_step(e.step_variant())) return -1;
   e.step_host++;
   ORL_HIP(hipStreamSynchronize(e.stream));
   if (metrics) {
@@ -835,15 +868,19 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   Engine& e = h->e;
   ORL_HIP(hipSetDevice(e.dev));
   if (n_steps <= 0) return fail("n_steps must be positive");
+  if (!e.buf || !e.buf->obs) return fail("orl_learn_n: no replay buffer attached");
   ORL_HIP(hipMemsetAsync(e.metrics_sum, 0, sizeof(float) * e.R * e.nm, e.stream));
   const bool graphable = e.use_graph && !e.prof_on;
-  if (graphable && !e.graph_exec) {
-    ORL_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
-    int rc = e.enqueue_sample(nullptr) || e.enqueue_noise() || e.enqueue_step();
-    hipError_t ce = hipStreamEndCapture(e.stream, &e.graph);
-    if (rc) return -1;
-    if (ce != hipSuccess) return fail(std::string("graph capture: ") + hipGetErrorString(ce));
-    ORL_HIP(hipGraphInstantiate(&e.graph_exec, e.graph, nullptr, nullptr, 0));
+  if (graphable) {
+    for (int v = 0; v < e.n_variants(); ++v) {
+      if (e.graph_exec[v]) continue;
+      ORL_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      int rc = e.enqueue_sample() || e.enqueue_noise() || e.enqueue_step(v);
+      hipError_t ce = hipStreamEndCapture(e.stream, &e.graph[v]);
+      if (rc) return -1;
+      if (ce != hipSuccess) return fail(std::string("graph capture: ") + hipGetErrorString(ce));
+      ORL_HIP(hipGraphInstantiate(&e.graph_exec[v], e.graph[v], nullptr, nullptr, 0));
+    }
   }
   hipEvent_t t0, t1;
   ORL_HIP(hipEventCreate(&t0));
@@ -851,16 +888,17 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   if (e.prof_on) { e.prof.clear(); e.ev_used = 0; }
   ORL_HIP(hipEventRecord(t0, e.stream));
   for (int s = 0; s < n_steps; ++s) {
-    if (graphable) { ORL_HIP(hipGraphLaunch(e.graph_exec, e.stream)); }
+    const int v = e.step_variant();
+    if (graphable) { ORL_HIP(hipGraphLaunch(e.graph_exec[v], e.stream)); }
     else {
-      if (e.enqueue_sample(nullptr)) return -1;
+      if (e.enqueue_sample()) return -1;
       if (e.enqueue_noise()) return -1;
-      if (e.enqueue_step()) return -1;
+      if (e.enqueue_step(v)) return -1;
     }
+    e.step_host++;
   }
   ORL_HIP(hipEventRecord(t1, e.stream));
   ORL_HIP(hipStreamSynchronize(e.stream));
-  e.step_host += n_steps;
   float ms = 0.f;
   ORL_HIP(hipEventElapsedTime(&ms, t0, t1));
   hipEventDestroy(t0); hipEventDestroy(t1);
@@ -914,11 +952,11 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
 }
 
 // kernel unit test: C = op(A) op(B) through one tile configuration.
-//  mode 0: forward   C[M,N] = A[M,K] B[N,K]^T + v0[N] (bias), relu
+//  mode 0: forward   C[M,N] = relu(A[M,K] B[N,K]^T + v0[N])
 //  mode 1: dgrad     C[M,N] = A[M,K] Bm[K,N], masked by v0 viewed [M,N] (>0)
-//  mode 2: wgrad     C[M,N+1]: C[:, :N] = A[K,M]^T B[K,N], C[:, N] = column sums of A ; split-K slabs summed on host
+//  mode 2: wgrad     A is [K,M], B is [K,N]: C = [A^T B (M*N) | column sums of A (M)]; split-K slabs summed on host
 //  mode 3: rank-1 dgrad  A_eff[m,k] = A[m,k]>0 ? v0[m]*v1[k] : 0 ; C = A_eff Bm[K,N]
-//  mode 4: rank-1 wgrad  A_eff[k,m] as above (A is [K,M]) ; C[M,N+1] like mode 2
+//  mode 4: rank-1 wgrad  A_eff[k,m] = A[k,m]>0 ? v0[k]*v1[m] : 0 ; output like mode 2
 int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* Bh, const float* v0, const float* v1,
                    float* C, int ksplit, int precision) {
   if (precision != 0) return fail("precision 1 not built");
@@ -942,7 +980,7 @@ int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const
   if (n1) { ORL_HIP(hipMalloc(&d1, sizeof(float) * n1)); ORL_HIP(hipMemcpy(d1, v1, sizeof(float) * n1, hipMemcpyHostToDevice)); }
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.nz1 = 1; p.ksplit = ksplit; p.C = dC; p.c_ks = nC;
+  p.nz1 = 1; p.ksplit = ksplit; p.C = dC; p.c_ks = nC; p.c_sn = 1;
   hipError_t err = hipSuccess;
   if (mode == 0) {
     p.A = {dA, 0, 0}; p.a_sr = K; p.a_sk = 1; p.B = {dB, 0, 0}; p.b_sr = K; p.b_sk = 1;

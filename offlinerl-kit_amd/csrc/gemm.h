@@ -44,6 +44,7 @@ struct GemmP {
   float* C;
   long c_s0, c_s1;   // z strides of C
   long c_sr;         // row stride of C (E_WGRAD: row stride of the weight-grad matrix = K_in)
+  long c_sn;         // column stride of C (1 except for EnsembleLinear (in,out)-major weight gradients)
   long c_ks;         // split-K slab stride of C (elements)
   int M, N, K;
   long a_sr, a_sk;   // A[m*a_sr + k*a_sk]
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
         if (EPI == E_BIAS_RELU) { v += bias[n]; v = v > 0.f ? v : 0.f; }
         if (EPI == E_MASK) v = aux[(long)m * p.aux_sr + n] > 0.f ? v : 0.f;
         if (EPI == E_WGRAD) {
-          if (n < p.ones_row) Cg[(long)m * p.c_sr + n] = v;
+          if (n < p.ones_row) Cg[(long)m * p.c_sr + (long)n * p.c_sn] = v;
           else if (n == p.ones_row && bo) bo[m] = v;
         } else {
-          Cg[(long)m * p.c_sr + n] = v;
+          Cg[(long)m * p.c_sr + (long)n * p.c_sn] = v;
         }
       }
     }

@@ -54,39 +54,75 @@ struct Hyper {                          // mutable hyper-parameters (orl_set_lr)
 __global__ void k_tick(unsigned long long* gstep) { *gstep += 1ull; }
 
 // ------------------------------------------------------------------------------------------------
-// replay gather (buffer.py:96-106).  SoA in HBM, rows padded to 16 B so one row = whole float4 loads.
-// idx == nullptr -> Philox indices (np.random.randint(0, size, B) restated on device).
-// grid (ceil(B/64), R), block 256: 4 threads per row cooperate.
+// replay gather (buffer.py:96-106).  Dataset = SoA in HBM, rows padded to 16 B (obs/next_obs pitch OP,
+// act pitch AP).  idx == nullptr -> Philox indices (np.random.randint(0, size, B) restated on device).
+// One thread per (row, column) of the widest array; consecutive lanes read consecutive floats of a row
+// (coalesced within the row) and rows are independent random 64-128 B segments.
+// grid (ceil(B*W/256), R) with W = max(OP, AP).
 // ------------------------------------------------------------------------------------------------
 struct GatherP {
   const float *obs, *nobs, *act, *rew, *term;  // dataset [n][OP], [n][OP], [n][AP], [n], [n]
   long n;
-  int OP, AP, od, ad, B;
-  const long long* idx;                         // [R][B] or null
-  float *b_obs, *b_nobs, *b_act, *b_rew, *b_term;  // batch slots [R][B][OP] ...
+  int OP, AP, od, ad, B, W;
+  const long long* idx; long idx_rs;           // [R][B] or null
+  float *b_obs, *b_nobs, *b_act, *b_rew, *b_term;  // destinations
+  long obs_rs, nobs_rs, act_rs, rew_rs, term_rs;   // run strides of the destinations
+  int d_op, d_ap;                                  // destination row pitches (>= od / ad; extra columns zeroed)
   unsigned long long seed;
   const unsigned long long* gstep;
+  unsigned long long counter;                      // used when gstep == nullptr
 };
 __global__ void k_gather(GatherP p) {
   const int r = blockIdx.y;
-  const int row = blockIdx.x * 64 + (threadIdx.x >> 2);
-  const int sub = threadIdx.x & 3;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = t / p.W, c = t - row * p.W;
   if (row >= p.B) return;
   long j;
-  if (p.idx) j = p.idx[(long)r * p.B + row];
+  if (p.idx) j = p.idx[(long)r * p.idx_rs + row];
   else {
-    Philox ph(p.seed);
+    const unsigned long long ctr = p.gstep ? *p.gstep : p.counter;
+    Philox ph(p.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
     uint32_t o[4];
-    ph((uint32_t)row, (uint32_t)r, (uint32_t)(*p.gstep), 0x1D5u ^ (uint32_t)((*p.gstep) >> 32), o);
+    ph((uint32_t)row, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
     j = (long)(((unsigned long long)o[0] * (unsigned long long)p.n) >> 32);
   }
-  const long dst = (long)r * p.B + row;
-  for (int c = sub * 4; c < p.OP; c += 16) {
-    *(float4*)&p.b_obs[dst * p.OP + c] = *(const float4*)&p.obs[j * p.OP + c];
-    *(float4*)&p.b_nobs[dst * p.OP + c] = *(const float4*)&p.nobs[j * p.OP + c];
+  if (c < p.d_op) {
+    const float vo = c < p.od ? p.obs[j * p.OP + c] : 0.f, vn = c < p.od ? p.nobs[j * p.OP + c] : 0.f;
+    p.b_obs[(long)r * p.obs_rs + (long)row * p.d_op + c] = vo;
+    p.b_nobs[(long)r * p.nobs_rs + (long)row * p.d_op + c] = vn;
   }
-  for (int c = sub * 4; c < p.AP; c += 16) *(float4*)&p.b_act[dst * p.AP + c] = *(const float4*)&p.act[j * p.AP + c];
-  if (sub == 0) { p.b_rew[dst] = p.rew[j]; p.b_term[dst] = p.term[j]; }
+  if (c < p.d_ap) p.b_act[(long)r * p.act_rs + (long)row * p.d_ap + c] = c < p.ad ? p.act[j * p.AP + c] : 0.f;
+  if (c == 0) { p.b_rew[(long)r * p.rew_rs + row] = p.rew[j]; p.b_term[(long)r * p.term_rs + row] = p.term[j]; }
+}
+
+// normalize_obs (buffer.py:88-94): per-column mean / population std in double, then in-place scaling
+__global__ void k_colstats(const float* x, long n, int pitch, int dim, double* sums /*[2*dim]*/) {
+  __shared__ double sh[2][256];
+  const int c = blockIdx.y;
+  double s = 0.0, q = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double v = x[i * pitch + c];
+    s += v; q += v * v;
+  }
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(&sums[c], sh[0][0]); atomicAdd(&sums[dim + c], sh[1][0]); }
+}
+__global__ void k_normalize(float* x, float* y, long n, int pitch, int dim, const float* mean, const float* stdv) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long i = t / dim; const int c = (int)(t - i * dim);
+  if (i >= n) return;
+  x[i * pitch + c] = (x[i * pitch + c] - mean[c]) / stdv[c];
+  y[i * pitch + c] = (y[i * pitch + c] - mean[c]) / stdv[c];
+}
+
+__global__ void k_fill(float* p, long n, float v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
 
 // device noise: fills `n` floats per run with N(0,1) (kind 0) or U[lo,hi) (kind 1)
@@ -387,7 +423,7 @@ struct AdamP {
   float* params; long p_s0, p_s1;     // [z0][z1][P]
   float* m; float* v;                 // same strides as params
   const float* g; long g_s0, g_s1, g_ks;
-  int nseg; long seg_end[8]; int seg_nslab[8];   // per-tensor-group split-K slab counts
+  int nseg; long seg_end[12]; int seg_nslab[12];   // per-tensor-group split-K slab counts
   float* target; long t_s0, t_s1;     // Polyak target or null
   long P;
   int lr_slot; const Hyper* hy;
@@ -430,6 +466,285 @@ __global__ void k_polyak(float* target, long t_s0, long t_s1, const float* src, 
   float* t = target + blockIdx.z * t_s0 + blockIdx.y * t_s1 + i;
   const float w = src[blockIdx.z * s_s0 + blockIdx.y * s_s1 + i];
   *t = *t * (1.0f - tau) + w * tau;
+}
+
+
+// ================================================================================================
+// IQL (iql.py:86-139; oracle/iql.py)
+// ================================================================================================
+struct MetricsP { float* last; float* sum; int nm; };
+__device__ inline void metric_set(const MetricsP& m, int r, int slot, float v) {
+  m.last[(long)r * m.nm + slot] = v; m.sum[(long)r * m.nm + slot] += v;
+}
+
+// value loss: diff = min(q1_old,q2_old) - v ; w = diff>0 ? tau_e : 1-tau_e ; L = mean(w diff^2) ; dv = -2 w diff / B
+struct IqlVP {
+  const float* qo; long qo_rs, qo_cs;   // [R][2][B] target critics at (s,a)
+  const float* v; long v_rs;            // [R][B]
+  float* dv;                            // [R][B]
+  float* qmin; long qmin_rs;            // [R][B] keeps min(q_old) for the actor weights
+  int B; float expectile; MetricsP m; int slot;
+};
+__global__ void k_iql_v_loss(IqlVP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    const float* q = p.qo + (long)r * p.qo_rs + b;
+    const float qm = fminf(q[0], q[p.qo_cs]);
+    const float d = qm - p.v[(long)r * p.v_rs + b];
+    const float w = d > 0.f ? p.expectile : 1.0f - p.expectile;
+    s += w * d * d;
+    p.dv[(long)r * p.v_rs + b] = -2.0f * w * d / (float)p.B;
+    p.qmin[(long)r * p.qmin_rs + b] = qm;
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) metric_set(p.m, r, p.slot, s / (float)p.B);
+}
+
+// Q losses + advantage weights: y = r + gamma (1-d) V_new(s') ; dq_i = 2 (q_i - y)/B ;
+// exp_a = min(exp((min q_old - V_new(s)) * beta), 100)
+struct IqlQP {
+  const float* q; long q_rs, q_cs;      // [R][2][B]
+  float* dq;
+  const float* v2; long v2_rs;          // [R][2B]: rows [0,B) V_new(s), [B,2B) V_new(s')
+  const float* qmin; long qmin_rs;
+  const float* rew; const float* term; long bt_rs;
+  float* exp_a; long ea_rs;             // [R][B]
+  float* target_q; long tq_rs;
+  int B; float gamma, beta; MetricsP m; int slot_q1, slot_q2;
+};
+__global__ void k_iql_q_loss(IqlQP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    const float* v2 = p.v2 + (long)r * p.v2_rs;
+    const float y = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * v2[p.B + b];
+    p.target_q[(long)r * p.tq_rs + b] = y;
+    const float* q = p.q + (long)r * p.q_rs + b;
+    float* dq = p.dq + (long)r * p.q_rs + b;
+    const float d1 = q[0] - y, d2 = q[p.q_cs] - y;
+    s1 += d1 * d1; s2 += d2 * d2;
+    dq[0] = 2.0f * d1 / (float)p.B; dq[p.q_cs] = 2.0f * d2 / (float)p.B;
+    p.exp_a[(long)r * p.ea_rs + b] = fminf(expf((p.qmin[(long)r * p.qmin_rs + b] - v2[b]) * p.beta), 100.0f);
+  }
+  s1 = block_sum256(s1, sh);
+  s2 = block_sum256(s2, sh);
+  if (threadIdx.x == 0) { metric_set(p.m, r, p.slot_q1, s1 / (float)p.B); metric_set(p.m, r, p.slot_q2, s2 / (float)p.B); }
+}
+
+// actor: mu = tanh(m_raw), sigma = exp(sigma_param); L = -mean(exp_a * logp(a_data)); writes d m_raw and the
+// sigma_param gradient (one slab) directly.
+struct IqlAP {
+  const float* mraw; long mraw_rs;      // [R][B][A]
+  const float* act; long act_rs; int apitch;
+  const float* exp_a; long ea_rs;
+  const float* sigma_param; long sp_rs; // [R][A] (inside the actor parameter block)
+  float* dmraw;                         // [R][B][A]
+  float* g_sigma; long gs_rs;           // [R][A] gradient slab 0 of sigma_param
+  int B, A; MetricsP m; int slot;
+};
+__global__ void k_iql_actor_loss(IqlAP p) {
+  __shared__ float sh[4];
+  __shared__ float gsig[64];
+  const int r = blockIdx.x;
+  const int A = p.A;
+  for (int a = threadIdx.x; a < A; a += 256) gsig[a] = 0.f;
+  __syncthreads();
+  float s = 0.f;
+  const float* sp = p.sigma_param + (long)r * p.sp_rs;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    const float ea = p.exp_a[(long)r * p.ea_rs + b];
+    const float dlogp = -ea / (float)p.B;
+    float lp = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float mu = tanhf(p.mraw[(long)r * p.mraw_rs + (long)b * A + a]);
+      const float ls = sp[a], sg = expf(ls), var = sg * sg;
+      const float d = p.act[(long)r * p.act_rs + (long)b * p.apitch + a] - mu;
+      lp += -(d * d) / (2.0f * var) - ls - ORL_LOG_SQRT_2PI;
+      p.dmraw[(long)r * p.mraw_rs + (long)b * A + a] = dlogp * d / var * (1.0f - mu * mu);
+      atomicAdd(&gsig[a], dlogp * (d * d / var - 1.0f));
+    }
+    s += ea * lp;
+  }
+  s = block_sum256(s, sh);
+  __syncthreads();
+  for (int a = threadIdx.x; a < A; a += 256) p.g_sigma[(long)r * p.gs_rs + a] = gsig[a];
+  if (threadIdx.x == 0) metric_set(p.m, r, p.slot, -s / (float)p.B);
+}
+
+// ================================================================================================
+// TD3+BC (td3bc.py:83-124; oracle/td3bc.py)
+// ================================================================================================
+// deterministic actor output: a = max_action * tanh(m_raw) (+ clipped target-policy noise), written into a
+// critic-input matrix.  grid (ceil(B*A/256), R)
+struct DetActP {
+  const float* mraw; long mraw_rs;       // [R][B][A]
+  const float* eps; long eps_rs;         // [R][B][A] or null
+  float* X; long x_rs; int XP, od;       // actions -> X[b*XP + od + a]
+  int B, A; float max_action, policy_noise, noise_clip;
+};
+__global__ void k_det_action(DetActP p) {
+  const int r = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.B * p.A) return;
+  const int b = t / p.A, a = t - b * p.A;
+  float v = p.max_action * tanhf(p.mraw[(long)r * p.mraw_rs + t]);
+  if (p.eps) {
+    const float nz = fminf(fmaxf(p.eps[(long)r * p.eps_rs + t] * p.policy_noise, -p.noise_clip), p.noise_clip);
+    v = fminf(fmaxf(v + nz, -p.max_action), p.max_action);
+  }
+  p.X[(long)r * p.x_rs + (long)b * p.XP + p.od + a] = v;
+}
+
+// twin-critic TD loss (also IQL-free algorithms): y = r + gamma (1-d) (min_c qt_c - alpha*logp_next) ; dq_c = 2 (q_c - y)/B
+struct TdLossP {
+  const float* q; long q_rs, q_cs; float* dq;    // [R][K][B]
+  const float* qt; long qt_rs, qt_cs; int Kt;    // target critics [R][Kt][Bt]
+  const float* rew; const float* term; long bt_rs;
+  const float* logp_next; long lpn_rs;           // or null
+  float* target_q; long tq_rs;
+  int B, K, rep;                                 // rep > 1: max over `rep` repeated next actions before the min
+  float gamma; int sum_over_k;                   // EDAC: one metric = sum_k mean_b ; else metric slot per critic
+  const RunScalars* sc; int use_alpha; int auto_alpha; float fixed_alpha;
+  MetricsP m; int slot0; float last_actor_loss_slot_unused;
+};
+__global__ void k_td_loss(TdLossP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  const int B = p.B;
+  const float alpha = p.auto_alpha ? p.sc[r].alpha : p.fixed_alpha;
+  float* tq = p.target_q + (long)r * p.tq_rs;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float nq = INFINITY;
+    for (int c = 0; c < p.Kt; ++c) {
+      const float* t = p.qt + (long)r * p.qt_rs + (long)c * p.qt_cs;
+      float v = -INFINITY;
+      for (int n = 0; n < p.rep; ++n) v = fmaxf(v, t[b * p.rep + n]);
+      nq = fminf(nq, v);
+    }
+    if (p.use_alpha && p.logp_next) nq -= alpha * p.logp_next[(long)r * p.lpn_rs + b];
+    tq[b] = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int c = 0; c < p.K; ++c) {
+    const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
+    float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
+    float s = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const float d = q[b] - tq[b];
+      s += d * d;
+      dq[b] = 2.0f * d / (float)B;
+    }
+    s = block_sum256(s, sh);
+    if (p.sum_over_k) total += s / (float)B;
+    else if (threadIdx.x == 0) metric_set(p.m, r, p.slot0 + c, s / (float)B);
+  }
+  if (p.sum_over_k && threadIdx.x == 0) metric_set(p.m, r, p.slot0, total);
+}
+
+// TD3BC actor objective pieces: lambda = alpha / mean|q| ; L = -lambda mean(q) + mean((a_pi - a)^2) ; dq = -lambda/B
+struct Td3ActorP {
+  const float* q; long q_rs;             // [R][B] critic1(s, pi(s))
+  float* dq;
+  const float* xa; long xa_rs; int XP, od;  // pi(s) in xa[:, od:]
+  const float* act; long act_rs; int apitch;
+  int B, A; float alpha; RunScalars* sc; MetricsP m; int slot;
+};
+__global__ void k_td3_actor_loss(Td3ActorP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float sq = 0.f, sabs = 0.f, sbc = 0.f;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    const float q = p.q[(long)r * p.q_rs + b];
+    sq += q; sabs += fabsf(q);
+    for (int a = 0; a < p.A; ++a) {
+      const float d = p.xa[(long)r * p.xa_rs + (long)b * p.XP + p.od + a] - p.act[(long)r * p.act_rs + (long)b * p.apitch + a];
+      sbc += d * d;
+    }
+  }
+  sq = block_sum256(sq, sh); sabs = block_sum256(sabs, sh); sbc = block_sum256(sbc, sh);
+  const float lmbda = p.alpha / (sabs / (float)p.B);
+  for (int b = threadIdx.x; b < p.B; b += 256) p.dq[(long)r * p.q_rs + b] = -lmbda / (float)p.B;
+  if (threadIdx.x == 0) {
+    const float loss = -lmbda * (sq / (float)p.B) + sbc / (float)(p.B * p.A);
+    p.sc[r].last_actor_loss = loss;
+    metric_set(p.m, r, p.slot, loss);
+  }
+}
+// critic-only steps report the last actor loss (td3bc.py:120)
+__global__ void k_td3_report_last(const RunScalars* sc, MetricsP m, int slot) {
+  const int r = blockIdx.x;
+  if (threadIdx.x == 0) metric_set(m, r, slot, sc[r].last_actor_loss);
+}
+// d m_raw = (dQ/da + 2 (a_pi - a)/(B A)) * max_action * (1 - tanh^2)
+struct Td3ActorBwdP {
+  const float* dxa; long dxa_rs; int dxa_pitch;   // [R][B][A]
+  const float* xa; long xa_rs; int XP, od;
+  const float* act; long act_rs; int apitch;
+  float* dmraw; long dm_rs;
+  int B, A; float max_action;
+};
+__global__ void k_td3_actor_bwd(Td3ActorBwdP p) {
+  const int r = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.B * p.A) return;
+  const int b = t / p.A, a = t - b * p.A;
+  const float ap = p.xa[(long)r * p.xa_rs + (long)b * p.XP + p.od + a];
+  const float da = p.dxa[(long)r * p.dxa_rs + (long)b * p.dxa_pitch + a] + 2.0f * (ap - p.act[(long)r * p.act_rs + (long)b * p.apitch + a]) / (float)(p.B * p.A);
+  const float th = ap / p.max_action;
+  p.dmraw[(long)r * p.dm_rs + t] = da * p.max_action * (1.0f - th * th);
+}
+
+// ================================================================================================
+// EDAC gradient-diversity term (edac.py:136-149; oracle/edac.py): from g[k][b][:] = dQ_k/da
+//   L_g = mean_b sum_{i!=j} <g^_i, g^_j> / (K-1) ; gamma = d(eta L_g)/dg.   One thread per batch row.
+// grid (ceil(B/64), R), block 64; K*A <= 640 values per row kept in registers/LDS-free loops.
+// ================================================================================================
+struct EdacGP {
+  const float* g; long g_rs, g_cs; int gpitch;   // [R][K][B][A]
+  float* gamma;                                   // same layout
+  int B, K, A; float eta; MetricsP m; int slot;
+};
+__global__ void k_edac_gamma(EdacGP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float sl = 0.f;
+  for (int b = threadIdx.x; b < p.B; b += 256) {
+    float S[32];
+    for (int a = 0; a < p.A; ++a) S[a] = 0.f;
+    float sum_sq = 0.f;
+    for (int k = 0; k < p.K; ++k) {
+      const float* gk = p.g + (long)r * p.g_rs + (long)k * p.g_cs + (long)b * p.gpitch;
+      float n2 = 0.f;
+      for (int a = 0; a < p.A; ++a) n2 += gk[a] * gk[a];
+      const float nk = sqrtf(n2) + 1e-10f;
+      for (int a = 0; a < p.A; ++a) S[a] += gk[a] / nk;
+      sum_sq += n2 / (nk * nk);
+    }
+    float ss = 0.f;
+    for (int a = 0; a < p.A; ++a) ss += S[a] * S[a];
+    sl += ss - sum_sq;
+    const float cf = p.eta * 2.0f / (float)((p.K - 1) * p.B);
+    for (int k = 0; k < p.K; ++k) {
+      const float* gk = p.g + (long)r * p.g_rs + (long)k * p.g_cs + (long)b * p.gpitch;
+      float* ok = p.gamma + (long)r * p.g_rs + (long)k * p.g_cs + (long)b * p.gpitch;
+      float n2 = 0.f;
+      for (int a = 0; a < p.A; ++a) n2 += gk[a] * gk[a];
+      const float nrm = sqrtf(n2), nk = nrm + 1e-10f;
+      float gc = 0.f;
+      for (int a = 0; a < p.A; ++a) gc += gk[a] * cf * (S[a] - gk[a] / nk);
+      const float safe = nrm > 0.f ? nrm : 1.0f;
+      for (int a = 0; a < p.A; ++a) ok[a] = cf * (S[a] - gk[a] / nk) / nk - gk[a] * (gc / (nk * nk * safe));
+    }
+  }
+  sl = block_sum256(sl, sh);
+  if (threadIdx.x == 0) {
+    const float lg = p.eta * (sl / (float)p.B) / (float)(p.K - 1);
+    p.m.last[(long)r * p.m.nm + p.slot] += lg; p.m.sum[(long)r * p.m.nm + p.slot] += lg;
+  }
 }
 
 }  // namespace orl

@@ -28,8 +28,8 @@ ABI_SYMBOLS = [
     "orl_last_error", "orl_version", "orl_config_default", "orl_arena_floats", "orl_engine_create",
     "orl_engine_destroy", "orl_engine_sync", "orl_net_present", "orl_net_floats", "orl_net_num_tensors",
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
-    "orl_set_lr", "orl_reset_optimizers", "orl_buffer_load", "orl_buffer_normalize_obs", "orl_buffer_sample",
-    "orl_buffer_size", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
+    "orl_set_lr", "orl_reset_optimizers", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
+    "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
     "orl_debug_read", "orl_debug_gemm", "orl_profile_enable", "orl_profile_query",
 ]
 
@@ -101,11 +101,15 @@ def load_library(path: Optional[str] = None):
     lib.orl_scalar_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.orl_set_lr.argtypes = [C.c_void_p, C.c_int, C.c_float]
     lib.orl_reset_optimizers.argtypes = [C.c_void_p]
+    lib.orl_buffer_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.orl_buffer_destroy.argtypes = [C.c_void_p]
+    lib.orl_buffer_destroy.restype = None
     lib.orl_buffer_load.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64]
     lib.orl_buffer_normalize_obs.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
-    lib.orl_buffer_sample.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(OrlBatch)]
+    lib.orl_buffer_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64] + [C.c_void_p] * 5
     lib.orl_buffer_size.argtypes = [C.c_void_p]
     lib.orl_buffer_size.restype = C.c_int64
+    lib.orl_engine_attach_buffer.argtypes = [C.c_void_p, C.c_void_p]
     lib.orl_step.argtypes = [C.c_void_p, C.POINTER(OrlBatch), C.POINTER(OrlNoise), C.c_void_p]
     lib.orl_learn_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
     lib.orl_num_metrics.argtypes = [C.c_void_p]
@@ -232,21 +236,9 @@ class Engine:
         _check(self.lib.orl_reset_optimizers(self._h), "orl_reset_optimizers")
 
     # ---- buffer ----
-    def buffer_load(self, obs, act, next_obs, rew, term):
-        obs, act, next_obs = _f32(obs), _f32(act), _f32(next_obs)
-        rew, term = _f32(rew).ravel(), _f32(term).ravel()
-        n = obs.shape[0]
-        _check(self.lib.orl_buffer_load(self._h, obs.ctypes.data, act.ctypes.data, next_obs.ctypes.data,
-                                        rew.ctypes.data, term.ctypes.data, n), "orl_buffer_load")
-
-    def buffer_sample(self, idx: Optional[np.ndarray] = None) -> OrlBatch:
-        out = OrlBatch()
-        p = None
-        if idx is not None:
-            idx = np.ascontiguousarray(idx, dtype=np.int64)
-            p = idx.ctypes.data
-        _check(self.lib.orl_buffer_sample(self._h, p, C.byref(out)), "orl_buffer_sample")
-        return out
+    def attach_buffer(self, buf: "DeviceBuffer"):
+        _check(self.lib.orl_engine_attach_buffer(self._h, buf._h if buf is not None else None), "orl_engine_attach_buffer")
+        self._buf = buf   # keep alive
 
     # ---- hot path ----
     def step(self, batch: Optional[Dict[str, np.ndarray]], noise: Optional[List[np.ndarray]], on_device=False) -> np.ndarray:
@@ -312,6 +304,54 @@ class Engine:
             rows.append(dict(name=name.value.decode(), total_ms=tot.value, launches=cnt.value, flops_per_launch=fl.value))
             i += 1
         return rows
+
+
+class DeviceBuffer:
+    """RAII wrapper over ``orl_buffer*``: the HBM-resident SoA replay store (buffer/buffer.py)."""
+
+    def __init__(self, obs_dim: int, act_dim: int, device: int = 0):
+        self.lib = load_library()
+        self.obs_dim, self.act_dim, self.device = obs_dim, act_dim, device
+        self._h = C.c_void_p()
+        _check(self.lib.orl_buffer_create(obs_dim, act_dim, device, C.byref(self._h)), "orl_buffer_create")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.orl_buffer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load(self, obs, act, next_obs, rew, term):
+        obs, act, next_obs = _f32(obs), _f32(act), _f32(next_obs)
+        rew, term = _f32(rew).ravel(), _f32(term).ravel()
+        n = obs.shape[0]
+        assert obs.shape == (n, self.obs_dim) and next_obs.shape == (n, self.obs_dim) and act.shape == (n, self.act_dim)
+        assert rew.size == n and term.size == n
+        _check(self.lib.orl_buffer_load(self._h, obs.ctypes.data, act.ctypes.data, next_obs.ctypes.data,
+                                        rew.ctypes.data, term.ctypes.data, n), "orl_buffer_load")
+
+    def size(self) -> int:
+        return self.lib.orl_buffer_size(self._h)
+
+    def normalize_obs(self, eps: float = 1e-3):
+        mean = np.zeros(self.obs_dim, dtype=np.float32)
+        std = np.zeros(self.obs_dim, dtype=np.float32)
+        _check(self.lib.orl_buffer_normalize_obs(self._h, float(eps), mean.ctypes.data, std.ctypes.data), "orl_buffer_normalize_obs")
+        return mean, std
+
+    def sample_into(self, idx, batch: int, seed: int, obs_ptr: int, act_ptr: int, nobs_ptr: int, rew_ptr: int, term_ptr: int):
+        """Gather into caller-owned device arrays (raw device pointers)."""
+        p = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int64)
+            assert idx.size == batch
+            p = idx.ctypes.data
+        _check(self.lib.orl_buffer_sample(self._h, p, batch, seed, obs_ptr, act_ptr, nobs_ptr, rew_ptr, term_ptr), "orl_buffer_sample")
 
 
 def debug_gemm(cfg: int, mode: int, A, B, v0=None, v1=None, ksplit=1, precision=0, M=None, N=None, K=None) -> np.ndarray:

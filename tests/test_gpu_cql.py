@@ -5,17 +5,11 @@ import numpy as np
 import pytest
 
 import synth
-from helpers import load_golden, cql_oracle_setup, rel_err, check_state_against_golden, clone_state
+from helpers import load_golden, cql_oracle_setup, rel_err, scale_err, check_state_against_golden, clone_state
 
 pytestmark = pytest.mark.gpu
 
 NETS = {"actor": 0, "critic1": 1, "critic2": 2, "critic1_old": 3, "critic2_old": 4}
-
-
-def scale_err(a, b):
-    a = np.asarray(a, np.float64).ravel()
-    b = np.asarray(b, np.float64).ravel()
-    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
 def make_engine(case, n_runs=1):
@@ -117,7 +111,9 @@ def test_cql_learn_n_device_sampling_runs_and_is_finite():
     eng, cfg, st, batches, noises = make_engine(case, n_runs=2)
     c = synth.CQL_CASES[case]
     ds = synth.make_dataset(3, 5000, c["obs_dim"], c["act_dim"])
-    eng.buffer_load(ds["observations"], ds["actions"], ds["next_observations"], ds["rewards"], ds["terminals"].astype(np.float32))
+    buf = _engine.DeviceBuffer(c["obs_dim"], c["act_dim"])
+    buf.load(ds["observations"], ds["actions"], ds["next_observations"], ds["rewards"], ds["terminals"].astype(np.float32))
+    eng.attach_buffer(buf)
     m, ms = eng.learn_n(50)
     assert np.isfinite(m).all() and ms > 0
     assert eng.step_count() == 50
