@@ -76,6 +76,13 @@ def load_library(path: Optional[str] = None):
     if not os.path.exists(p):
         raise RuntimeError(f"native update engine not built: {p} is missing "
                            f"(run `python offlinerl-kit_amd/build.py` or __graft_entry__.build())")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7.  Import torch FIRST so that this library's
+    # NEEDED libamdhip64.so.7 binds to the runtime already in the process; loading the engine first would put
+    # a second HIP runtime (/opt/rocm's) beside torch's and torch would then report "No HIP GPUs are available".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.orl_last_error.restype = C.c_char_p
     lib.orl_version.restype = C.c_char_p
