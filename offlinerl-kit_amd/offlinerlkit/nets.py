@@ -1,0 +1,76 @@
+"""Backbone networks of the hot path (reference: offlinerlkit/nets/mlp.py:9-33, nets/ensemble_linear.py:9-41).
+
+These torch modules only DESCRIBE a network (shapes, initial weights, eval-time forward for
+``select_action``).  Training never runs through them: an engine-backed policy copies their
+parameters into the HIP engine's arena and re-points ``param.data`` at views of that arena.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+
+class MLP(nn.Module):
+    """[Linear, activation(, Dropout)] x len(hidden_dims) (+ optional output Linear).
+    ``self.model`` is an ``nn.Sequential`` so state_dict keys are ``model.<2*i>.{weight,bias}`` like the reference."""
+
+    def __init__(self, input_dim: int, hidden_dims: Sequence[int], output_dim: Optional[int] = None,
+                 activation=nn.ReLU, dropout_rate: Optional[float] = None) -> None:
+        super().__init__()
+        widths = [int(input_dim)] + [int(h) for h in hidden_dims]
+        layers: List[nn.Module] = []
+        for fan_in, fan_out in zip(widths, widths[1:]):
+            layers.append(nn.Linear(fan_in, fan_out))
+            layers.append(activation())
+            if dropout_rate is not None:
+                layers.append(nn.Dropout(p=dropout_rate))
+        self.output_dim = widths[-1]
+        if output_dim is not None:
+            layers.append(nn.Linear(widths[-1], int(output_dim)))
+            self.output_dim = int(output_dim)
+        self.activation_cls = activation
+        self.dropout_rate = dropout_rate
+        self.model = nn.Sequential(*layers)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.model(x)
+
+    def linear_layers(self) -> List[nn.Linear]:
+        return [m for m in self.model if isinstance(m, nn.Linear)]
+
+
+class EnsembleLinear(nn.Module):
+    """K independent affine maps evaluated together: weight (K, in, out), bias (K, 1, out); y = x @ W + b.
+    A 2-D input is shared by every member.  ``saved_weight`` / ``saved_bias`` are the reference's shadow copies
+    (ensemble_linear.py:25-26): registered so state_dict keys match, never trained."""
+
+    def __init__(self, input_dim: int, output_dim: int, num_ensemble: int, weight_decay: float = 0.0) -> None:
+        super().__init__()
+        self.num_ensemble = num_ensemble
+        self.weight_decay = weight_decay
+        w = torch.zeros(num_ensemble, input_dim, output_dim)
+        nn.init.trunc_normal_(w, std=1.0 / (2.0 * input_dim ** 0.5))
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(num_ensemble, 1, output_dim))
+        self.saved_weight = nn.Parameter(self.weight.detach().clone())
+        self.saved_bias = nn.Parameter(self.bias.detach().clone())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 2:
+            y = torch.einsum("ij,bjk->bik", x, self.weight)
+        else:
+            y = torch.bmm(x, self.weight)
+        return y + self.bias
+
+    def load_save(self) -> None:
+        self.weight.data.copy_(self.saved_weight.data)
+        self.bias.data.copy_(self.saved_bias.data)
+
+    def update_save(self, indexes) -> None:
+        self.saved_weight.data[indexes] = self.weight.data[indexes]
+        self.saved_bias.data[indexes] = self.bias.data[indexes]
+
+    def get_decay_loss(self) -> torch.Tensor:
+        return self.weight_decay * 0.5 * (self.weight ** 2).sum()

@@ -1,0 +1,131 @@
+"""MFPolicyTrainer (reference: offlinerlkit/policy_trainer/mf_policy_trainer.py:17-118).
+
+Same constructor, same logged keys, same per-epoch order (train steps -> lr_scheduler.step -> evaluate -> log ->
+checkpoint) and the same return value.  Two inner loops:
+  * ``fused=False``: the reference's loop verbatim — ``buffer.sample`` (numpy index stream) -> ``policy.learn``
+    -> ``logger.logkv_mean`` per step, one host sync per step;
+  * ``fused=True`` (default when the policy offers ``learn_n`` and the buffer is HBM-resident): the whole epoch's
+    sample -> learn chain runs on the device and only the epoch means come back — the values ``logkv_mean`` would
+    have accumulated (only per-epoch means are ever consumed).
+Multi-GPU: independent runs, one process per GPU (replicas only).  When ``torch.distributed`` is initialised the
+per-epoch metric vector of every rank is all-gathered (RCCL over xGMI on GPUs, gloo on CPU) so rank 0 can log
+all runs; no other collective exists on this path.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import deque
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+
+class MFPolicyTrainer:
+    def __init__(self, policy, eval_env, buffer, logger, epoch: int = 1000, step_per_epoch: int = 1000, batch_size: int = 256,
+                 eval_episodes: int = 10, lr_scheduler=None, fused: Optional[bool] = None, progress: bool = False) -> None:
+        self.policy = policy
+        self.eval_env = eval_env
+        self.buffer = buffer
+        self.logger = logger
+        self._epoch = epoch
+        self._step_per_epoch = step_per_epoch
+        self._batch_size = batch_size
+        self._eval_episodes = eval_episodes
+        self.lr_scheduler = lr_scheduler
+        if fused is None:
+            fused = hasattr(policy, "learn_n") and hasattr(buffer, "device_buffer")
+        self._fused = fused
+        self._progress = progress
+        self.gathered_metrics: List[Dict[str, np.ndarray]] = []   # per epoch: key -> value of every rank
+
+    # ---- inner loops -----------------------------------------------------------------------
+    def _train_epoch(self, e: int) -> int:
+        if self._fused:
+            means = self.policy.learn_n(self._step_per_epoch, self.buffer, self._batch_size)
+            for k, v in means.items():
+                self.logger.logkv(k, v)
+            return self._step_per_epoch
+        it = range(self._step_per_epoch)
+        if self._progress:
+            from tqdm import tqdm
+            it = tqdm(it, desc=f"Epoch #{e}/{self._epoch}")
+        for _ in it:
+            batch = self.buffer.sample(self._batch_size)
+            loss = self.policy.learn(batch)
+            if self._progress:
+                it.set_postfix(**loss)
+            for k, v in loss.items():
+                self.logger.logkv_mean(k, v)
+        return self._step_per_epoch
+
+    def _gather(self, kv: Dict[str, float]) -> None:
+        """End-of-epoch metric all-gather: every rank contributes its metric vector, rank 0 logs ``rank<i>/<key>``."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        keys = sorted(kv)
+        backend = dist.get_backend()
+        dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+        mine = torch.tensor([float(kv[k]) for k in keys], dtype=torch.float32, device=dev)
+        out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        table = torch.stack(out).cpu().numpy()
+        self.gathered_metrics.append({k: table[:, i].copy() for i, k in enumerate(keys)})
+        if dist.get_rank() == 0:
+            for r in range(table.shape[0]):
+                for i, k in enumerate(keys):
+                    self.logger.logkv(f"rank{r}/{k}", float(table[r, i]))
+
+    # ---- reference API ---------------------------------------------------------------------
+    def train(self) -> Dict[str, float]:
+        start_time = time.time()
+        num_timesteps = 0
+        last_10_performance = deque(maxlen=10)
+        for e in range(1, self._epoch + 1):
+            self.policy.train()
+            num_timesteps += self._train_epoch(e)
+            if self.lr_scheduler is not None:
+                self.lr_scheduler.step()
+            eval_info = self._evaluate()
+            ep_reward_mean, ep_reward_std = np.mean(eval_info["eval/episode_reward"]), np.std(eval_info["eval/episode_reward"])
+            ep_length_mean, ep_length_std = np.mean(eval_info["eval/episode_length"]), np.std(eval_info["eval/episode_length"])
+            epoch_kv = dict(self.logger._name2val) if hasattr(self.logger, "_name2val") else {}
+            if hasattr(self.eval_env, "get_normalized_score"):
+                norm_ep_rew_mean = self.eval_env.get_normalized_score(ep_reward_mean) * 100
+                norm_ep_rew_std = self.eval_env.get_normalized_score(ep_reward_std) * 100
+                last_10_performance.append(norm_ep_rew_mean)
+                self.logger.logkv("eval/normalized_episode_reward", norm_ep_rew_mean)
+                self.logger.logkv("eval/normalized_episode_reward_std", norm_ep_rew_std)
+                epoch_kv["eval/normalized_episode_reward"] = norm_ep_rew_mean
+            self.logger.logkv("eval/episode_reward", ep_reward_mean)
+            self.logger.logkv("eval/episode_reward_std", ep_reward_std)
+            self.logger.logkv("eval/episode_length", ep_length_mean)
+            self.logger.logkv("eval/episode_length_std", ep_length_std)
+            epoch_kv["eval/episode_reward"] = ep_reward_mean
+            self._gather({k: v for k, v in epoch_kv.items() if isinstance(v, (int, float, np.floating))})
+            self.logger.set_timestep(num_timesteps)
+            self.logger.dumpkvs()
+            torch.save(self.policy.state_dict(), os.path.join(self.logger.checkpoint_dir, "policy.pth"))
+        self.logger.log("total time: {:.2f}s".format(time.time() - start_time))
+        torch.save(self.policy.state_dict(), os.path.join(self.logger.model_dir, "policy.pth"))
+        self.logger.close()
+        return {"last_10_performance": np.mean(last_10_performance)}
+
+    def _evaluate(self) -> Dict[str, List[float]]:
+        self.policy.eval()
+        obs = self.eval_env.reset()
+        done_eps: List[Dict[str, float]] = []
+        ep_reward, ep_len = 0, 0
+        while len(done_eps) < self._eval_episodes:
+            action = self.policy.select_action(obs.reshape(1, -1), deterministic=True)
+            obs, reward, terminal, _ = self.eval_env.step(action.flatten())
+            ep_reward += reward
+            ep_len += 1
+            if terminal:
+                done_eps.append({"episode_reward": ep_reward, "episode_length": ep_len})
+                ep_reward, ep_len = 0, 0
+                obs = self.eval_env.reset()
+        return {"eval/episode_reward": [d["episode_reward"] for d in done_eps],
+                "eval/episode_length": [d["episode_length"] for d in done_eps]}
