@@ -47,6 +47,7 @@ struct NetLayout {
   long b_ms[ORL_MAX_HIDDEN + 1] = {0};
   long extra_off = -1;                   // IQL sigma_param
   long size = 0;                         // floats of ONE net (ens: of the whole ensemble)
+  long stride() const { return (size + 3) & ~3L; }   // arena stride: keeps every net 16-B aligned
   std::vector<TensorInfo> tensors;
   int layer_in(int l) const { return l == 0 ? in_dim : H[l - 1]; }
   int layer_out(int l) const { return l == L ? out_dim : H[l]; }
@@ -124,6 +125,7 @@ struct Engine {
   hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
   hipGraph_t graph[2] = {nullptr, nullptr};
   bool use_graph = true;
+  bool force_scalar = false;   // debug: disable the vector loaders
 
   ~Engine();
   int init(const orl_config& c);

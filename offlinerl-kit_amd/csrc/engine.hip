@@ -79,7 +79,7 @@ static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind 
     l.b_off[L] = off; add_tensor(l, "last.bias", off, {act_dim}); off += act_dim;
   }
   l.size = off;
-  for (int i = 0; i <= L; ++i) l.w_ms[i] = l.b_ms[i] = l.size;
+  for (int i = 0; i <= L; ++i) l.w_ms[i] = l.b_ms[i] = l.stride();
   return l;
 }
 
@@ -113,8 +113,8 @@ static int build_layouts(const orl_config& c, NetLayout* lay, long* net_off, boo
   const int od = c.obs_dim, ad = c.act_dim, L = c.n_hidden;
   const NetLayout crit = make_mlp_layout(od + ad, c.hidden, L, TAIL_CRITIC, ad);
   long o = 0, t = 0;
-  auto train = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = o; o += l.size; };
-  auto target = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = t; is_tgt[id] = true; t += l.size; };
+  auto train = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = o; o += l.stride(); };
+  auto target = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = t; is_tgt[id] = true; t += l.stride(); };
   if (c.algo == ORL_ALGO_CQL) {
     train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_TANH_GAUSS, ad));
     train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
@@ -232,10 +232,10 @@ void Engine::prof_end() {
   } while (0)
 
 template <int PA, int PB, int EPI>
-static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag) {
+static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag, bool a_kpad = false) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
   e->prof_begin(tag, flops);
-  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream);
+  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar);
   e->prof_end();
   if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
   return 0;
@@ -259,19 +259,20 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   memset(&p, 0, sizeof(p));
   p.A = {X.p, X.rs, X.cs};
   p.a_sr = X.pitch; p.a_sk = 1;
-  if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)in_row0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = out; }
+  if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)in_row0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = out; p.b_rlim = out & ~3; }
   else { p.B = {nr.base + l.w_off[layer] + in_row0, nr.rs, l.w_ms[layer]}; p.b_sr = in; p.b_sk = 1; }
   p.C = Y.p; p.c_s0 = Y.rs; p.c_s1 = Y.cs; p.c_sr = Y.pitch; p.c_sn = 1;
   p.M = M; p.N = out; p.K = in_rows;
+  const bool a_kpad = X.pitch >= ((in_rows + 3) & ~3);   // input matrices are zero-padded to 16 B rows
   p.nz1 = nr.nz1; p.ksplit = 1;
   p.bias = {nr.base + l.b_off[layer], nr.rs, l.b_ms[layer]};
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
   const int nz = R * nr.nz1;
   switch (epi) {
-    case E_BIAS_RELU: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, CFG_AUTO, p, nz, tag);
-    case E_BIAS: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS>(this, CFG_AUTO, p, nz, tag);
-    case E_MASK: return run_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
-    default: return run_gemm<PA_PLAIN, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
+    case E_BIAS_RELU: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, CFG_AUTO, p, nz, tag, a_kpad);
+    case E_BIAS: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS>(this, CFG_AUTO, p, nz, tag, a_kpad);
+    case E_MASK: return run_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag, a_kpad);
+    default: return run_gemm<PA_PLAIN, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag, a_kpad);
   }
 }
 
@@ -289,7 +290,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     p.colv = {nr.base + l.w_off[l.L], nr.rs, l.w_ms[l.L]};
   }
   if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)col0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = out; p.b_sk = 1; }
-  else { p.B = {nr.base + l.w_off[layer] + col0, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = in; }
+  else { p.B = {nr.base + l.w_off[layer] + col0, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = in; p.b_rlim = (in - col0) & ~3; }
   p.C = dX.p; p.c_s0 = dX.rs; p.c_s1 = dX.cs; p.c_sr = dX.pitch; p.c_sn = 1;
   p.M = M; p.N = ncols; p.K = out;
   p.nz1 = nr.nz1; p.ksplit = 1;
@@ -338,6 +339,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   }
   p.B = {X.p, X.rs, X.cs};
   p.b_sr = 1; p.b_sk = X.pitch;
+  p.a_rlim = dy.m.pitch & ~3; p.b_rlim = X.pitch & ~3;
   p.ones_row = in_rows;
   p.M = out; p.N = in_rows + (with_bias ? 1 : 0); p.K = M;
   p.nz1 = nr.nz1; p.ksplit = ksplit;
@@ -356,13 +358,13 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   AdamP a;
   memset(&a, 0, sizeof(a));
   const NetLayout& l = lay[net];
-  a.params = net_ptr(0, net); a.p_s0 = P_train; a.p_s1 = l.size;
+  a.params = net_ptr(0, net); a.p_s0 = P_train; a.p_s1 = l.stride();
   a.m = adam_m + net_off[net]; a.v = adam_v + net_off[net];
-  a.g = grads + net_off[net]; a.g_s0 = (long)max_slab * P_train; a.g_s1 = l.size; a.g_ks = P_train;
+  a.g = grads + net_off[net]; a.g_s0 = (long)max_slab * P_train; a.g_s1 = l.stride(); a.g_ks = P_train;
   a.nseg = (int)segs.size();
   if (a.nseg > 12) return fail("too many adam segments");
   for (int i = 0; i < a.nseg; ++i) { a.seg_end[i] = segs[i].first; a.seg_nslab[i] = segs[i].second; }
-  if (target_net >= 0) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.size; }
+  if (target_net >= 0) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.stride(); }
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
   a.b1 = cfg.adam_beta1; a.b2 = cfg.adam_beta2; a.eps = cfg.adam_eps; a.tau = cfg.tau;
   a.gstep = gstep; a.t_div = t_div;
@@ -371,9 +373,9 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
 }
 
 int Engine::polyak(int target_net, int src_net, int nnets) {
-  const long P = lay[src_net].size;
-  ORL_LAUNCH("polyak", k_polyak, dim3((unsigned)((P + 255) / 256), nnets, R), dim3(256), net_ptr(0, target_net), P_tgt, P,
-             (const float*)net_ptr(0, src_net), P_train, P, P, cfg.tau);
+  const long P = lay[src_net].size, PS = lay[src_net].stride();
+  ORL_LAUNCH("polyak", k_polyak, dim3((unsigned)((P + 255) / 256), nnets, R), dim3(256), net_ptr(0, target_net), P_tgt, PS,
+             (const float*)net_ptr(0, src_net), P_train, PS, P, cfg.tau);
   return 0;
 }
 
@@ -874,7 +876,7 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   if (graphable) {
     for (int v = 0; v < e.n_variants(); ++v) {
       if (e.graph_exec[v]) continue;
-      ORL_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeThreadLocal));
+      ORL_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeRelaxed));
       int rc = e.enqueue_sample() || e.enqueue_noise() || e.enqueue_step(v);
       hipError_t ce = hipStreamEndCapture(e.stream, &e.graph[v]);
       if (rc) return -1;
@@ -981,22 +983,25 @@ int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.nz1 = 1; p.ksplit = ksplit; p.C = dC; p.c_ks = nC; p.c_sn = 1;
+  const bool fs = (cfg & 16) != 0;      // bit 4 of cfg forces the scalar loaders (unit tests cover both paths)
+  cfg &= 15;
+  p.a_rlim = M & ~3; p.b_rlim = N & ~3;
   hipError_t err = hipSuccess;
   if (mode == 0) {
     p.A = {dA, 0, 0}; p.a_sr = K; p.a_sk = 1; p.B = {dB, 0, 0}; p.b_sr = K; p.b_sk = 1;
     p.M = M; p.N = N; p.K = K; p.c_sr = N; p.bias = {d0, 0, 0};
-    err = launch_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(cfg, p, 1, st);
+    err = launch_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(cfg, p, 1, st, false, fs);
   } else if (mode == 1 || mode == 3) {
     p.A = {dA, 0, 0}; p.a_sr = K; p.a_sk = 1; p.B = {dB, 0, 0}; p.b_sr = 1; p.b_sk = N;
     p.M = M; p.N = N; p.K = K; p.c_sr = N;
-    if (mode == 1) { p.aux = {d0, 0, 0}; p.aux_sr = N; err = launch_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(cfg, p, 1, st); }
-    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 0; err = launch_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(cfg, p, 1, st); }
+    if (mode == 1) { p.aux = {d0, 0, 0}; p.aux_sr = N; err = launch_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(cfg, p, 1, st, false, fs); }
+    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 0; err = launch_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(cfg, p, 1, st, false, fs); }
   } else {
     p.A = {dA, 0, 0}; p.a_sr = 1; p.a_sk = M; p.B = {dB, 0, 0}; p.b_sr = 1; p.b_sk = N;
     p.M = M; p.N = N + 1; p.K = K; p.c_sr = N; p.ones_row = N;
     p.bias_out = dC + (long)M * N; p.bo_ks = nC;
-    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(cfg, p, 1, st);
-    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_ONES, E_WGRAD>(cfg, p, 1, st); }
+    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs);
+    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs); }
   }
   if (err != hipSuccess) return fail(std::string("debug gemm launch: ") + hipGetErrorString(err));
   ORL_HIP(hipDeviceSynchronize());

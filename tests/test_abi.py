@@ -39,8 +39,9 @@ def test_config_struct_matches_c_layout(lib):
     assert cfg.batch_size == 256 and cfg.num_repeat_actions == 10
     assert abs(cfg.cql_weight - 5.0) < 1e-7 and abs(cfg.actor_lr - 1e-4) < 1e-9 and abs(cfg.critic_lr - 3e-4) < 1e-9
     assert abs(cfg.eta - 1.0) < 1e-7 and cfg.num_critics == 10 and cfg.external_arena is None
-    # parameter inventory of SURVEY Appendix B: actor 73 484, critic 72 193 (x2 trainable + x2 targets)
-    assert lib.orl_arena_floats(ctypes.byref(cfg)) == 73484 + 4 * 72193
+    # parameter inventory of SURVEY Appendix B: actor 73 484, critic 72 193 (x2 trainable + x2 targets);
+    # each net's arena stride is padded to 4 floats (16-B aligned nets -> vector loads)
+    assert lib.orl_arena_floats(ctypes.byref(cfg)) == 73484 + 4 * 72196
 
 
 def test_engine_create_fails_loudly_without_gpu(lib):

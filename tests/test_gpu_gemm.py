@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL = 0, 1, 2, 3
-SHAPES = [(64, 256, 32), (70, 40, 23), (256, 256, 256), (130, 17, 100), (16, 1, 256), (1, 33, 77), (300, 257, 129)]
+SHAPES = [(64, 256, 32), (70, 40, 23), (256, 256, 256), (130, 17, 100), (16, 1, 256), (1, 33, 77), (300, 257, 129), (128, 64, 96), (200, 24, 64), (513, 256, 260)]
 
 
 def _close(got, ref, tol=2e-5):
@@ -15,7 +15,7 @@ def _close(got, ref, tol=2e-5):
     assert np.abs(got - ref).max() / scale < tol, np.abs(got - ref).max() / scale
 
 
-@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL])
+@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL, CFG_BIG | 16, CFG_MID | 16, CFG_SMALL | 16, CFG_TALL | 16])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_forward_bias_relu(cfg, shape):
     from offlinerlkit._engine import debug_gemm
@@ -29,7 +29,7 @@ def test_forward_bias_relu(cfg, shape):
     _close(got, ref)
 
 
-@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL])
+@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL, CFG_BIG | 16, CFG_MID | 16, CFG_SMALL | 16, CFG_TALL | 16])
 @pytest.mark.parametrize("shape", SHAPES)
 def test_dgrad_masked_and_rank1(cfg, shape):
     from offlinerlkit._engine import debug_gemm
@@ -50,8 +50,8 @@ def test_dgrad_masked_and_rank1(cfg, shape):
     _close(got, dz.astype(np.float64) @ Wm.astype(np.float64))
 
 
-@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL])
-@pytest.mark.parametrize("shape", [(64, 64, 512), (256, 23, 1000), (1, 256, 300), (12, 256, 256), (40, 33, 77)])
+@pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL, CFG_BIG | 16, CFG_MID | 16, CFG_SMALL | 16, CFG_TALL | 16])
+@pytest.mark.parametrize("shape", [(64, 64, 512), (256, 23, 1000), (1, 256, 300), (12, 256, 256), (40, 33, 77), (256, 256, 1024), (32, 24, 640), (64, 256, 100)])
 @pytest.mark.parametrize("ksplit", [1, 3, 8])
 def test_wgrad_with_bias_column_and_splitk(cfg, shape, ksplit):
     from offlinerlkit._engine import debug_gemm
