@@ -118,6 +118,12 @@ struct Engine {
   std::map<std::string, Tap> taps;
   struct NoiseSlot { std::string name; int kind; int rows; };
   std::vector<NoiseSlot> noise_slots;
+  // k_prepare job list (algorithms that use it skip the separate gather / noise / assemble launches)
+  struct PrepSpec { PrepJob job; int need_sampling; int need_devnoise; };   // -1 any, 0 no, 1 yes
+  std::vector<PrepSpec> prep;
+  void add_prep(const Mat& dst, int row0, int col0, int rows, int width, int src, int rep, int mod, int ncopy, const Mat* buf,
+                unsigned stream_id, int need_sampling, int need_devnoise);
+  int enqueue_prepare(bool sampling, bool devnoise);
   bool prof_on = false;
   std::vector<ProfEntry> prof;
   std::vector<hipEvent_t> ev_pool;
@@ -126,6 +132,7 @@ struct Engine {
   hipGraph_t graph[2] = {nullptr, nullptr};
   bool use_graph = true;
   bool force_scalar = false;   // debug: disable the vector loaders
+  int loss_nblk = 1;
 
   ~Engine();
   int init(const orl_config& c);

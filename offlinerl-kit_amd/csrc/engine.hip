@@ -570,6 +570,47 @@ int Engine::enqueue_noise() {
   return 0;
 }
 
+void Engine::add_prep(const Mat& dst, int row0, int col0, int rows, int width, int src, int rep, int mod, int ncopy, const Mat* buf,
+                      unsigned stream_id, int need_sampling, int need_devnoise) {
+  PrepSpec s;
+  memset(&s, 0, sizeof(s));
+  s.job.dst = dst.p; s.job.dst_rs = dst.rs; s.job.dst_pitch = dst.pitch; s.job.dst_row0 = row0; s.job.dst_col0 = col0;
+  s.job.rows = rows; s.job.width = width; s.job.src = src; s.job.rep = rep; s.job.mod = mod; s.job.ncopy = ncopy;
+  if (buf) { s.job.buf = buf->p; s.job.buf_rs = buf->rs; s.job.buf_pitch = buf->pitch; }
+  s.job.stream_id = stream_id;
+  s.need_sampling = need_sampling; s.need_devnoise = need_devnoise;
+  prep.push_back(s);
+}
+
+int Engine::enqueue_prepare(bool sampling, bool devnoise) {
+  PrepP p;
+  memset(&p, 0, sizeof(p));
+  long total = 0;
+  for (auto& s : prep) {
+    if (s.need_sampling >= 0 && s.need_sampling != (int)sampling) continue;
+    if (s.need_devnoise >= 0 && s.need_devnoise != (int)devnoise) continue;
+    if (p.njobs >= 20) return fail("too many prepare jobs");
+    PrepJob j = s.job;
+    total += (long)j.rows * j.width;
+    j.elem_end = total;
+    p.job[p.njobs++] = j;
+  }
+  if (p.njobs == 0) return 0;
+  p.total = total;
+  if (sampling) {
+    if (!buf || !buf->obs) return fail("no replay buffer attached (orl_engine_attach_buffer)");
+    p.d_obs = buf->obs; p.d_nobs = buf->nobs; p.d_act = buf->act; p.d_rew = buf->rew; p.d_term = buf->term; p.n = buf->n;
+    p.OP = buf->OP; p.AP = buf->AP;
+  }
+  Mat o2 = W("b_obs2");
+  p.b_obs = o2.p; p.b_nobs = o2.p + (long)B * OP; p.bo_rs = o2.rs; p.b_op = OP;
+  p.b_act = W("b_act").p; p.ba_rs = W("b_act").rs; p.b_ap = AP;
+  p.b_rew = W("b_rew").p; p.b_term = W("b_term").p; p.br_rs = W("b_rew").rs;
+  p.B = B; p.seed = cfg.seed; p.gstep = gstep; p.lo = cfg.act_low; p.hi = cfg.act_high;
+  ORL_LAUNCH("prepare", k_prepare, dim3((unsigned)((total + 255) / 256), R), dim3(256), p);
+  return 0;
+}
+
 int Engine::n_variants() const { return cfg.algo == ORL_ALGO_TD3BC ? 2 : 1; }
 int Engine::step_variant() const {
   if (cfg.algo != ORL_ALGO_TD3BC) return 0;
@@ -851,9 +892,9 @@ int orl_step(orl_engine* h, const orl_batch* b, const orl_noise* nz, float* metr
     const bool dv = nz->on_device != 0;
     for (size_t i = 0; i < e.noise_slots.size(); ++i)
       if (copy_rows(e, e.W(e.noise_slots[i].name), nz->slot[i], e.noise_slots[i].rows, e.ad, dv)) return -1;
-  } else {
-    if (e.enqueue_noise()) return -1;
   }
+  if (!e.prep.empty()) { if (e.enqueue_prepare(false, nz == nullptr)) return -1; }
+  else if (!nz) { if (e.enqueue_noise()) return -1; }
   if (e.enqueue_step(e.step_variant())) return -1;
   e.step_host++;
   ORL_HIP(hipStreamSynchronize(e.stream));
@@ -877,7 +918,7 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
     for (int v = 0; v < e.n_variants(); ++v) {
       if (e.graph_exec[v]) continue;
       ORL_HIP(hipStreamBeginCapture(e.stream, hipStreamCaptureModeRelaxed));
-      int rc = e.enqueue_sample() || e.enqueue_noise() || e.enqueue_step(v);
+      int rc = (e.prep.empty() ? (e.enqueue_sample() || e.enqueue_noise()) : e.enqueue_prepare(true, true)) || e.enqueue_step(v);
       hipError_t ce = hipStreamEndCapture(e.stream, &e.graph[v]);
       if (rc) return -1;
       if (ce != hipSuccess) return fail(std::string("graph capture: ") + hipGetErrorString(ce));
@@ -893,8 +934,8 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
     const int v = e.step_variant();
     if (graphable) { ORL_HIP(hipGraphLaunch(e.graph_exec[v], e.stream)); }
     else {
-      if (e.enqueue_sample()) return -1;
-      if (e.enqueue_noise()) return -1;
+      if (e.prep.empty()) { if (e.enqueue_sample()) return -1; if (e.enqueue_noise()) return -1; }
+      else if (e.enqueue_prepare(true, true)) return -1;
       if (e.enqueue_step(v)) return -1;
     }
     e.step_host++;

@@ -142,6 +142,89 @@ __global__ void k_noise(float* out, long n_per_run, int kind, float lo, float hi
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_prepare: ONE launch that materialises every input of a step — replay gather (batch slots), critic-input
+// matrices X = (obs | act | 0-pad) with repeated rows, and all noise arrays — instead of 1 gather + N noise +
+// M assemble launches.  A job table (<= 16 entries, passed by value) describes the outputs; one thread per
+// output element.  Observation-like sources are read either straight from the HBM dataset through the Philox
+// (or host-supplied) index of the row (sampling mode) or from the batch slots (teacher-forced mode).
+// ------------------------------------------------------------------------------------------------
+enum { PS_OBS = 0, PS_NOBS = 1, PS_ACT = 2, PS_REW = 3, PS_TERM = 4, PS_NORMAL = 5, PS_UNIFORM = 6, PS_BUF = 7, PS_ZERO = 8 };
+struct PrepJob {
+  long elem_end;        // exclusive end of this job's element range (per run)
+  float* dst; long dst_rs; int dst_pitch, dst_row0, dst_col0;
+  int rows, width;      // output region: rows x width
+  int src;              // PS_*
+  int rep, mod;         // source row = (mod ? row % mod : row) / rep
+  int ncopy;            // columns [0, ncopy) come from the source, the rest of `width` is zero
+  const float* buf; long buf_rs; int buf_pitch;   // PS_BUF source
+  unsigned stream_id;   // noise stream
+};
+struct PrepP {
+  PrepJob job[20];
+  int njobs;
+  long total;           // elements per run
+  // dataset (sampling mode) or null -> batch slots
+  const float *d_obs, *d_nobs, *d_act, *d_rew, *d_term; long n; int OP, AP;
+  const long long* idx; long idx_rs;
+  const float *b_obs, *b_nobs, *b_act, *b_rew, *b_term; long bo_rs, ba_rs, br_rs; int b_op, b_ap;
+  int B;
+  unsigned long long seed; const unsigned long long* gstep; float lo, hi;
+};
+__global__ void k_prepare(PrepP p) {
+  const int r = blockIdx.y;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.total) return;
+  int ji = 0;
+  while (ji < p.njobs - 1 && t >= p.job[ji].elem_end) ++ji;
+  const PrepJob& jb = p.job[ji];
+  const long e = t - (ji ? p.job[ji - 1].elem_end : 0);
+  const int row = (int)(e / jb.width), col = (int)(e - (long)row * jb.width);
+  float v = 0.f;
+  const unsigned long long ctr = p.gstep ? *p.gstep : 0ull;
+  if (jb.src == PS_NORMAL || jb.src == PS_UNIFORM) {
+    // one Philox call yields 4 values: element e uses lane e&3 of counter e>>2
+    Philox ph(p.seed);
+    uint32_t o[4];
+    ph((uint32_t)(e >> 2), (uint32_t)r | (jb.stream_id << 16), (uint32_t)ctr, 0xA5u ^ (uint32_t)(ctr >> 32), o);
+    if (jb.src == PS_NORMAL) {
+      float n0, n1;
+      if ((e & 2) == 0) box_muller(o[0], o[1], n0, n1); else box_muller(o[2], o[3], n0, n1);
+      v = (e & 1) ? n1 : n0;
+    } else v = p.lo + (p.hi - p.lo) * u01(o[e & 3]);
+  } else if (jb.src == PS_BUF) {
+    if (col < jb.ncopy) v = jb.buf[(long)r * jb.buf_rs + (long)((jb.mod ? row % jb.mod : row) / jb.rep) * jb.buf_pitch + col];
+  } else if (jb.src != PS_ZERO && col < jb.ncopy) {
+    const int b = (jb.mod ? row % jb.mod : row) / jb.rep;
+    if (p.d_obs) {
+      long j;
+      if (p.idx) j = p.idx[(long)r * p.idx_rs + b];
+      else {
+        Philox ph(p.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
+        uint32_t o[4];
+        ph((uint32_t)b, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
+        j = (long)(((unsigned long long)o[0] * (unsigned long long)p.n) >> 32);
+      }
+      switch (jb.src) {
+        case PS_OBS: v = p.d_obs[j * p.OP + col]; break;
+        case PS_NOBS: v = p.d_nobs[j * p.OP + col]; break;
+        case PS_ACT: v = p.d_act[j * p.AP + col]; break;
+        case PS_REW: v = p.d_rew[j]; break;
+        default: v = p.d_term[j]; break;
+      }
+    } else {
+      switch (jb.src) {
+        case PS_OBS: v = p.b_obs[(long)r * p.bo_rs + (long)b * p.b_op + col]; break;
+        case PS_NOBS: v = p.b_nobs[(long)r * p.bo_rs + (long)b * p.b_op + col]; break;
+        case PS_ACT: v = p.b_act[(long)r * p.ba_rs + (long)b * p.b_ap + col]; break;
+        case PS_REW: v = p.b_rew[(long)r * p.br_rs + b]; break;
+        default: v = p.b_term[(long)r * p.br_rs + b]; break;
+      }
+    }
+  }
+  jb.dst[(long)r * jb.dst_rs + (long)(jb.dst_row0 + row) * jb.dst_pitch + jb.dst_col0 + col] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // critic-input assembly: X[row] = (obs_src[row / rep], act_src[row]) with pitch XP (zero padded)
 // grid (ceil(rows/256), R)
 // ------------------------------------------------------------------------------------------------
@@ -327,7 +410,10 @@ __global__ void k_head_bwd(HeadBwdP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// CQL critic loss + gradient seeds (cql.py:108-190, oracle/cql.py).  One block per run.
+// CQL critic loss + gradient seeds (cql.py:108-190, oracle/cql.py), two launches:
+//   k_cql_loss_rows: grid (nblk, 2 critics, R): logsumexp rows -> dq + partial sums; block 0 also does the B data
+//                    rows (TD target, dq, sums).  cons_scale (= pre-step cql_alpha) is known up front.
+//   k_cql_loss_fin : one block per run: reduces the partials in fixed order -> metrics, Lagrange Adam step.
 //   rows of q[c]: [0,B) data, [B,B+BN) pi, [B+BN,B+2BN) next-pi, [B+2BN,B+3BN) random
 // ------------------------------------------------------------------------------------------------
 struct CqlLossP {
@@ -338,6 +424,7 @@ struct CqlLossP {
   const float* logp_next; long lpn_rs;     // [R][B]   (stochastic backup)
   const float* logp_pi; const float* logp_npi; long lpp_rs;   // [R][BN]
   float* target_q; long tq_rs;             // [R][B] (tap)
+  float* part; int nblk;                   // partial sums [R][2][nblk][3] = (s_td, s_q, s_lse)
   int B, N, A;
   float gamma, w, T, thr;
   int max_q_backup, det_backup, with_lagrange, auto_alpha; float fixed_alpha;
@@ -346,66 +433,79 @@ struct CqlLossP {
   float* metrics_last; float* metrics_sum; int nm;
   int m_c1, m_c2, m_cqla_loss, m_cqla;
 };
-__global__ void k_cql_loss(CqlLossP p) {
+__global__ void k_cql_loss_rows(CqlLossP p) {
   __shared__ float sh[4];
-  const int r = blockIdx.x;
-  RunScalars& sc = p.sc[r];
+  const int blk = blockIdx.x, c = blockIdx.y, r = blockIdx.z;
+  const RunScalars& sc = p.sc[r];
   const int B = p.B, BN = p.B * p.N;
   const float alpha = p.auto_alpha ? sc.alpha : p.fixed_alpha;
-  float cs = 1.0f, e_cla = 0.f;
-  if (p.with_lagrange) { e_cla = expf(sc.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
+  float cs = 1.0f;
+  if (p.with_lagrange) cs = fminf(fmaxf(expf(sc.cql_log_alpha), 0.f), 1e6f);
   const float log_rand = logf(powf(0.5f, (float)p.A));
-  float* tq = p.target_q + (long)r * p.tq_rs;
-  // target_q
-  for (int b = threadIdx.x; b < B; b += 256) {
+  const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
+  float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
+  float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
+  if (blk == 0) {
     const float* t0 = p.qt + (long)r * p.qt_rs;
     const float* t1 = t0 + p.qt_cs;
-    float nq;
-    if (p.max_q_backup) {
-      float m0 = -INFINITY, m1 = -INFINITY;
-      for (int n = 0; n < p.N; ++n) { m0 = fmaxf(m0, t0[b * p.N + n]); m1 = fmaxf(m1, t1[b * p.N + n]); }
-      nq = fminf(m0, m1);
-    } else {
-      nq = fminf(t0[b], t1[b]);
-      if (!p.det_backup) nq -= alpha * p.logp_next[(long)r * p.lpn_rs + b];
-    }
-    tq[b] = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
-  }
-  __syncthreads();
-  float raw[2];
-  for (int c = 0; c < 2; ++c) {
-    const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
-    float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
-    float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
     for (int b = threadIdx.x; b < B; b += 256) {
-      const float d = q[b] - tq[b];
+      float nq;
+      if (p.max_q_backup) {
+        float m0 = -INFINITY, m1 = -INFINITY;
+        for (int n = 0; n < p.N; ++n) { m0 = fmaxf(m0, t0[b * p.N + n]); m1 = fmaxf(m1, t1[b * p.N + n]); }
+        nq = fminf(m0, m1);
+      } else {
+        nq = fminf(t0[b], t1[b]);
+        if (!p.det_backup) nq -= alpha * p.logp_next[(long)r * p.lpn_rs + b];
+      }
+      const float y = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
+      if (c == 0) p.target_q[(long)r * p.tq_rs + b] = y;
+      const float d = q[b] - y;
       s_td += d * d; s_q += q[b];
       dq[b] = 2.0f * d / (float)B - cs * p.w / (float)B;
     }
-    const float* lpp = p.logp_pi + (long)r * p.lpp_rs;
-    const float* lpn = p.logp_npi + (long)r * p.lpp_rs;
-    const float gs = cs * p.w / (float)BN;
-    for (int j = threadIdx.x; j < BN; j += 256) {
-      const float v0 = (q[B + j] - lpp[j]) / p.T, v1 = (q[B + BN + j] - lpn[j]) / p.T, v2 = (q[B + 2 * BN + j] - log_rand) / p.T;
-      const float mx = fmaxf(v0, fmaxf(v1, v2));
-      const float e0 = expf(v0 - mx), e1 = expf(v1 - mx), e2 = expf(v2 - mx);
-      const float se = e0 + e1 + e2;
-      s_lse += logf(se) + mx;
-      dq[B + j] = gs * (e0 / se); dq[B + BN + j] = gs * (e1 / se); dq[B + 2 * BN + j] = gs * (e2 / se);
-    }
-    s_td = block_sum256(s_td, sh);
-    s_q = block_sum256(s_q, sh);
-    s_lse = block_sum256(s_lse, sh);
+  }
+  const float* lpp = p.logp_pi + (long)r * p.lpp_rs;
+  const float* lpn = p.logp_npi + (long)r * p.lpp_rs;
+  const float gs = cs * p.w / (float)BN;
+  const int per = (BN + p.nblk - 1) / p.nblk;
+  const int j1 = min(BN, (blk + 1) * per);
+  for (int j = blk * per + threadIdx.x; j < j1; j += 256) {
+    const float v0 = (q[B + j] - lpp[j]) / p.T, v1 = (q[B + BN + j] - lpn[j]) / p.T, v2 = (q[B + 2 * BN + j] - log_rand) / p.T;
+    const float mx = fmaxf(v0, fmaxf(v1, v2));
+    const float e0 = expf(v0 - mx), e1 = expf(v1 - mx), e2 = expf(v2 - mx);
+    const float se = e0 + e1 + e2;
+    s_lse += logf(se) + mx;
+    dq[B + j] = gs * (e0 / se); dq[B + BN + j] = gs * (e1 / se); dq[B + 2 * BN + j] = gs * (e2 / se);
+  }
+  s_td = block_sum256(s_td, sh);
+  s_q = block_sum256(s_q, sh);
+  s_lse = block_sum256(s_lse, sh);
+  if (threadIdx.x == 0) {
+    float* o = p.part + (((long)r * 2 + c) * p.nblk + blk) * 3;
+    o[0] = s_td; o[1] = s_q; o[2] = s_lse;
+  }
+}
+__global__ void k_cql_loss_fin(CqlLossP p) {
+  const int r = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  RunScalars& sc = p.sc[r];
+  const int B = p.B, BN = p.B * p.N;
+  float cs = 1.0f, e_cla = 0.f;
+  if (p.with_lagrange) { e_cla = expf(sc.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
+  float raw[2];
+  for (int c = 0; c < 2; ++c) {
+    float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
+    const float* o = p.part + ((long)r * 2 + c) * p.nblk * 3;
+    for (int k = 0; k < p.nblk; ++k) { s_td += o[k * 3]; s_q += o[k * 3 + 1]; s_lse += o[k * 3 + 2]; }
     float cons = (s_lse / (float)BN) * p.w * p.T - (s_q / (float)B) * p.w;
     raw[c] = cons - p.thr;
     if (p.with_lagrange) cons = cs * raw[c];
-    if (threadIdx.x == 0) {
-      const float loss = s_td / (float)B + cons;
-      const int slot = c == 0 ? p.m_c1 : p.m_c2;
-      p.metrics_last[(long)r * p.nm + slot] = loss; p.metrics_sum[(long)r * p.nm + slot] += loss;
-    }
+    const float loss = s_td / (float)B + cons;
+    const int slot = c == 0 ? p.m_c1 : p.m_c2;
+    p.metrics_last[(long)r * p.nm + slot] = loss; p.metrics_sum[(long)r * p.nm + slot] += loss;
   }
-  if (p.with_lagrange && threadIdx.x == 0) {
+  if (p.with_lagrange) {
     const float l = -(cs * raw[0] + cs * raw[1]) * 0.5f;
     const float gate = (e_cla >= 0.f && e_cla <= 1e6f) ? 1.f : 0.f;
     const float g = -(raw[0] + raw[1]) * 0.5f * e_cla * gate;
