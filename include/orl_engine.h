@@ -185,6 +185,8 @@ int64_t orl_debug_read(orl_engine* e, int run, const char* name, float* host, in
 /* runs one generic GEMM tile configuration on host data (kernel unit tests): see csrc/gemm.h */
 int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* B, const float* v0,
                    const float* v1, float* C, int ksplit, int precision);
+/* times `reps` launches of one GEMM tile configuration on random data (kind 0 forward, 1 dgrad, 2 wgrad) */
+int orl_debug_gemm_time(int cfg, int kind, int M, int N, int K, int nz, int ksplit, int reps, float* ms_out);
 /* average duration (ms) of the kernel with the largest accumulated time during the last orl_learn_n
  * when profiling was enabled with orl_profile_enable(e,1); name copied to `name`. */
 int orl_profile_enable(orl_engine* e, int on);

@@ -101,7 +101,7 @@ struct Engine {
   float* adam_m = nullptr;
   float* adam_v = nullptr;
   float* grads = nullptr;      // [R][max_slab][P_train]
-  int max_slab = 32;
+  int max_slab = 64;
   RunScalars* scalars = nullptr;
   Hyper* hyper = nullptr;
   Hyper hyper_host;

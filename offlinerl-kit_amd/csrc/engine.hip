@@ -235,7 +235,7 @@ template <int PA, int PB, int EPI>
 static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag, bool a_kpad = false) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
   e->prof_begin(tag, flops);
-  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar);
+  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar, e->cfg.precision);
   e->prof_end();
   if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
   return 0;
@@ -306,9 +306,10 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
 
 // split-K factor for a weight gradient: enough workgroups to fill 256 CUs, chunk aligned
 static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
-  const int cfg = pick_cfg(Mout, Nout, Krows);
+  const int cfg = pick_cfg(Mout, Nout, Krows, nz);
   int TM, TN, TK;
   switch (cfg) {
+    case CFG_SQ: TM = CfgSq::TM; TN = CfgSq::TN; TK = CfgSq::kTK; break;
     case CFG_BIG: TM = CfgBig::TM; TN = CfgBig::TN; TK = CfgBig::kTK; break;
     case CFG_MID: TM = CfgMid::TM; TN = CfgMid::TN; TK = CfgMid::kTK; break;
     case CFG_SMALL: TM = CfgSmall::TM; TN = CfgSmall::TN; TK = CfgSmall::kTK; break;
@@ -495,7 +496,7 @@ int Engine::init(const orl_config& c) {
   if (c.device < 0 || c.device >= ndev) return fail("bad device ordinal");
   dev = c.device;
   ORL_HIP(hipSetDevice(dev));
-  if (c.precision != 0) return fail("precision=1 (split-bf16 MFMA) is not built yet; use precision=0 (fp32 MFMA)");
+  if (c.precision != 0 && c.precision != 1) return fail("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
   if (build_layouts(c, lay, net_off, net_is_target, &P_train, &P_tgt)) return -1;
   ORL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   R = c.n_runs; B = c.batch_size; od = c.obs_dim; ad = c.act_dim;
@@ -648,7 +649,7 @@ struct orl_buffer {
 extern "C" {
 
 const char* orl_last_error(void) { return g_err.c_str(); }
-const char* orl_version(void) { return "orl-engine 0.2 (gfx950, fp32 MFMA; CQL IQL TD3BC EDAC)"; }
+const char* orl_version(void) { return "orl-engine 0.3 (gfx950; fp32 MFMA + split-bf16 MFMA; CQL IQL TD3BC EDAC)"; }
 
 void orl_config_default(orl_config* c, int32_t algo) {
   memset(c, 0, sizeof(*c));
@@ -1002,7 +1003,7 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
 //  mode 4: rank-1 wgrad  A_eff[k,m] = A[k,m]>0 ? v0[k]*v1[m] : 0 ; output like mode 2
 int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* Bh, const float* v0, const float* v1,
                    float* C, int ksplit, int precision) {
-  if (precision != 0) return fail("precision 1 not built");
+  if (precision != 0 && precision != 1) return fail("precision must be 0 or 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device");
   hipStream_t st = nullptr;
@@ -1031,18 +1032,18 @@ int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const
   if (mode == 0) {
     p.A = {dA, 0, 0}; p.a_sr = K; p.a_sk = 1; p.B = {dB, 0, 0}; p.b_sr = K; p.b_sk = 1;
     p.M = M; p.N = N; p.K = K; p.c_sr = N; p.bias = {d0, 0, 0};
-    err = launch_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(cfg, p, 1, st, false, fs);
+    err = launch_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(cfg, p, 1, st, false, fs, precision);
   } else if (mode == 1 || mode == 3) {
     p.A = {dA, 0, 0}; p.a_sr = K; p.a_sk = 1; p.B = {dB, 0, 0}; p.b_sr = 1; p.b_sk = N;
     p.M = M; p.N = N; p.K = K; p.c_sr = N;
-    if (mode == 1) { p.aux = {d0, 0, 0}; p.aux_sr = N; err = launch_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(cfg, p, 1, st, false, fs); }
-    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 0; err = launch_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(cfg, p, 1, st, false, fs); }
+    if (mode == 1) { p.aux = {d0, 0, 0}; p.aux_sr = N; err = launch_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(cfg, p, 1, st, false, fs, precision); }
+    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 0; err = launch_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(cfg, p, 1, st, false, fs, precision); }
   } else {
     p.A = {dA, 0, 0}; p.a_sr = 1; p.a_sk = M; p.B = {dB, 0, 0}; p.b_sr = 1; p.b_sk = N;
     p.M = M; p.N = N + 1; p.K = K; p.c_sr = N; p.ones_row = N;
     p.bias_out = dC + (long)M * N; p.bo_ks = nC;
-    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs);
-    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs); }
+    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs, precision);
+    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs, precision); }
   }
   if (err != hipSuccess) return fail(std::string("debug gemm launch: ") + hipGetErrorString(err));
   ORL_HIP(hipDeviceSynchronize());
@@ -1054,6 +1055,62 @@ int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const
     C[i] = s;
   }
   hipFree(dA); hipFree(dB); hipFree(dC); if (d0) hipFree(d0); if (d1) hipFree(d1);
+  return 0;
+}
+
+// GEMM tuning tap: times `reps` launches of one tile configuration on random data of the hot-path shapes.
+//  kind 0: forward  (VECK,VECK, bias+relu)   C[M,N]   = relu(A[M,K] W[N,K]^T + b)
+//  kind 1: dgrad    (VECK,BLK4, rank-1, mask) C[M,N]   = ((H>0) dq w) W[K,N]  masked
+//  kind 2: wgrad    (BLK4,BLK4, rank-1, ones) C[M,N+1] = ((H>0) dq w)^T X     (M = out, K = rows), split-K
+int orl_debug_gemm_time(int cfg, int kind, int M, int N, int K, int nz, int ksplit, int reps, float* ms_out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device");
+  const long nA = (kind == 2) ? (long)K * M : (long)M * K;
+  const long nB = (kind == 0) ? (long)N * K : (kind == 1 ? (long)K * N : (long)K * N);
+  const long nC = (kind == 2) ? (long)M * (N + 1) * ksplit : (long)M * N;
+  float *dA, *dB, *dC, *dv0, *dv1, *dH;
+  ORL_HIP(hipMalloc(&dA, sizeof(float) * nA * nz));
+  ORL_HIP(hipMalloc(&dB, sizeof(float) * nB * nz));
+  ORL_HIP(hipMalloc(&dC, sizeof(float) * nC * nz));
+  ORL_HIP(hipMalloc(&dH, sizeof(float) * (long)M * N * nz));
+  ORL_HIP(hipMalloc(&dv0, sizeof(float) * (M + K + N) * nz));
+  ORL_HIP(hipMalloc(&dv1, sizeof(float) * (M + K + N) * nz));
+  std::vector<float> h(std::max(std::max(nA, nB), std::max((long)M * N, (long)(M + K + N))) * nz);
+  unsigned s = 12345u;
+  auto fill = [&](float* d, long n) { for (long i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = ((s >> 8) / 8388608.0f) - 1.0f; } return hipMemcpy(d, h.data(), sizeof(float) * n, hipMemcpyHostToDevice); };
+  ORL_HIP(fill(dA, nA * nz)); ORL_HIP(fill(dB, nB * nz)); ORL_HIP(fill(dH, (long)M * N * nz)); ORL_HIP(fill(dv0, (long)(M + K + N) * nz)); ORL_HIP(fill(dv1, (long)(M + K + N) * nz));
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.nz1 = nz; p.ksplit = ksplit; p.C = dC; p.c_sn = 1; p.c_s1 = nC;
+  p.A = {dA, 0, nA}; p.B = {dB, 0, nB};
+  p.rowv = {dv0, 0, (long)(M + K + N)}; p.colv = {dv1, 0, (long)(M + K + N)};
+  p.bias = {dv0, 0, (long)(M + K + N)}; p.aux = {dH, 0, (long)M * N}; p.aux_sr = N;
+  hipStream_t st = nullptr;
+  hipEvent_t e0, e1;
+  ORL_HIP(hipEventCreate(&e0)); ORL_HIP(hipEventCreate(&e1));
+  hipError_t err = hipSuccess;
+  for (int it = 0; it < reps + 3; ++it) {
+    if (it == 3) ORL_HIP(hipEventRecord(e0, st));
+    if (kind == 0) {
+      p.a_sr = K; p.a_sk = 1; p.b_sr = K; p.b_sk = 1; p.M = M; p.N = N; p.K = K; p.c_sr = N;
+      err = launch_tune(cfg, 0, p, nz, st);
+    } else if (kind == 1) {
+      p.a_sr = K; p.a_sk = 1; p.b_sr = 1; p.b_sk = N; p.b_rlim = N & ~3; p.M = M; p.N = N; p.K = K; p.c_sr = N; p.a_trans = 0;
+      err = launch_tune(cfg, 1, p, nz, st);
+    } else {
+      p.a_sr = 1; p.a_sk = M; p.b_sr = 1; p.b_sk = N; p.a_rlim = M & ~3; p.b_rlim = N & ~3; p.M = M; p.N = N + 1; p.K = K; p.c_sr = N;
+      p.ones_row = N; p.a_trans = 1; p.c_ks = (long)M * (N + 1); p.c_s1 = nC; p.bias_out = dC + (long)M * N; p.bo_s1 = nC; p.bo_ks = (long)M * (N + 1);
+      err = launch_tune(cfg, 2, p, nz, st);
+    }
+    if (err != hipSuccess) return fail(std::string("gemm_time launch: ") + hipGetErrorString(err));
+  }
+  ORL_HIP(hipEventRecord(e1, st));
+  ORL_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  ORL_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = ms / reps;
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dH); hipFree(dv0); hipFree(dv1);
   return 0;
 }
 

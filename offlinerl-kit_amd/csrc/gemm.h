@@ -32,6 +32,13 @@
 namespace orl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// precision of the multiply: P_F32 = v_mfma_f32_16x16x4_f32 (exact fp32);  P_BF16X3 = every operand split into
+// hi = bf16(x), lo = bf16(x - hi) while it is staged into LDS, product = lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per operand, 3/16 of the fp32 MFMA cycles)
+enum { P_F32 = 0, P_BF16X3 = 1 };
 
 enum { PA_PLAIN = 0, PA_RANK1 = 1 };                                   // prologue on A elements
 enum { PB_PLAIN = 0, PB_ONES = 1 };                                    // prologue on B elements
@@ -75,7 +82,11 @@ template <int WM, int WN, int MA, int NB, int TK>
 struct GemmCfg {
   static constexpr int kWM = WM, kWN = WN, kMA = MA, kNB = NB, kTK = TK;
   static constexpr int TM = WM * MA * 16, TN = WN * NB * 16, NT = WM * WN * 64, PITCH = TK + 4;
+  static constexpr int PITCH_H = TK + 8;                       // bf16 planes: row stride (TK+8)*2 B, 16-B aligned
   static constexpr int LDS_FLOATS = 2 * (TM + TN) * PITCH;
+  static constexpr size_t lds_bytes(int prec) {
+    return prec == P_F32 ? sizeof(float) * LDS_FLOATS : (size_t)2 /*buf*/ * 2 /*hi,lo*/ * (TM + TN) * PITCH_H * 2;
+  }
   static_assert(TK % 16 == 0, "TK multiple of 16");
 };
 
@@ -90,8 +101,14 @@ struct TileLoader {
   static constexpr int PER_THREAD = (NSLOTS + NT - 1) / NT;
   static constexpr bool EXACT = (NSLOTS % NT) == 0;
   float reg[PER_THREAD * SLOT_ELEMS];
+  // loop-invariant per-slot state, computed once by init(): the K loop only adds a uniform k offset
+  int goff[PER_THREAD];     // element offset of the slot's first element at k0 = 0 (row already clamped)
+  int loff[PER_THREAD];     // LDS offset of the slot's first element
+  int kin[PER_THREAD];      // k of the slot inside a chunk
+  int grow[PER_THREAD];     // clamped global row (rank-1 prologue) 
+  int ones[PER_THREAD];     // PB_ONES: bit rr set -> row (r + rr) is the virtual ones row
+  long sk_;
 
-  // slot -> (row, k) of its first element
   __device__ static inline void slot_rk(int e, bool k_contig, int& r, int& k) {
     if (LMODE == L_VECK) { constexpr int Q = TK / 4; k = 4 * (e % Q); r = e / Q; }
     else if (LMODE == L_BLK4) { constexpr int Q = ROWS / 4; r = 4 * (e % Q); k = 4 * (e / Q); }
@@ -99,101 +116,146 @@ struct TileLoader {
     else { r = e % ROWS; k = e / ROWS; }
   }
 
-  // TAIL = false: the whole chunk [k0, k0+TK) is inside K (no k checks)
-  template <bool TAIL>
-  __device__ inline void load(const GemmP& p, const float* __restrict__ g, const float* __restrict__ rowv,
-                              const float* __restrict__ colv, int row0, int k0, int tid) {
+  __device__ inline void init(const GemmP& p, int row0, int tid) {
     const long sr = IS_A ? p.a_sr : p.b_sr, sk = IS_A ? p.a_sk : p.b_sk;
+    sk_ = sk;
     // rows that exist in memory: the wgrad "ones" row (bias-gradient column) is virtual and must never be read
     const int nrows = IS_A ? p.M : ((PRO == PB_ONES && p.ones_row < p.N) ? p.ones_row : p.N);
+    const int rlim = IS_A ? p.a_rlim : p.b_rlim;
     const bool k_contig = (sk == 1);
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       const int e = tid + i * NT;
-      if (!EXACT && e >= NSLOTS) break;
-      int r, k;
-      slot_rk(e, k_contig, r, k);
-      const int gk = k0 + k;
+      int r = 0, k = 0;
+      slot_rk(EXACT ? e : (e < NSLOTS ? e : 0), k_contig, r, k);
+      int gr = row0 + r;
+      if (LMODE == L_BLK4) gr = gr <= rlim - 4 ? gr : rlim - 4;
+      else gr = gr < nrows ? gr : nrows - 1;
+      grow[i] = gr;
+      kin[i] = k;
+      loff[i] = r * PITCH + k;
+      goff[i] = (LMODE == L_BLK4) ? (int)((long)k * sk + gr) : (int)((long)gr * sr + (long)k * sk);
+      int om = 0;
+      if (PRO == PB_ONES && !IS_A) {
+        if (LMODE == L_BLK4) { for (int rr = 0; rr < 4; ++rr) om |= (row0 + r + rr == p.ones_row) ? (1 << rr) : 0; }
+        else om = (row0 + r == p.ones_row) ? 1 : 0;
+      }
+      ones[i] = om;
+    }
+  }
+
+  // TAIL = false: the whole chunk [k0, k0+TK) is inside K (no k checks)
+  template <bool TAIL>
+  __device__ inline void load(const GemmP& p, const float* __restrict__ g, const float* __restrict__ rowv,
+                              const float* __restrict__ colv, int k0, int tid) {
+    const long sk = sk_;
+    const float* __restrict__ gk0 = g + (long)k0 * sk;      // uniform per chunk
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      if (!EXACT && tid + i * NT >= NSLOTS) break;
+      const int gk = k0 + kin[i];
       float* o = &reg[i * SLOT_ELEMS];
       if (LMODE == L_SCALAR) {
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;
-        const int kk = TAIL ? (gk < p.K ? gk : p.K - 1) : gk;
-        float v = g[(long)gr * sr + (long)kk * sk];
+        const bool kv = !TAIL || gk < p.K;
+        float v = kv ? gk0[goff[i]] : g[goff[i] - (long)kin[i] * sk];          // clamped in-bounds address
         if (PRO == PA_RANK1 && IS_A) {
-          const int mm = p.a_trans ? kk : gr, nn = p.a_trans ? gr : kk;
+          const int kk = kv ? gk : 0;
+          const int mm = p.a_trans ? kk : grow[i], nn = p.a_trans ? grow[i] : kk;
           v = v > 0.f ? rowv[mm] * colv[nn] : 0.f;
         }
-        if (PRO == PB_ONES && !IS_A) v = (row0 + r == p.ones_row) ? 1.f : v;
-        if (TAIL) v = gk < p.K ? v : 0.f;
-        o[0] = v;
+        if (PRO == PB_ONES && !IS_A) v = ones[i] ? 1.f : v;
+        o[0] = kv ? v : 0.f;
       } else if (LMODE == L_VECK) {
-        int gr = row0 + r;
-        gr = gr < nrows ? gr : nrows - 1;
-        const int kk = TAIL ? (gk < p.K ? gk : 0) : gk;     // K % 4 == 0 or zero-padded rows (host guarantees)
-        f32x4 v = *(const f32x4*)&g[(long)gr * sr + kk];
+        const bool kv = !TAIL || gk < p.K;               // K % 4 == 0 or zero-padded rows (host guarantees)
+        const float* src = kv ? gk0 + goff[i] : g + goff[i] - kin[i];
+        f32x4 v = *(const f32x4*)src;
         if (PRO == PA_RANK1 && IS_A) {
-          const float rv = rowv[gr];
-          const f32x4 cv = *(const f32x4*)&colv[kk];
+          const float rv = rowv[grow[i]];
+          const f32x4 cv = *(const f32x4*)&colv[kv ? gk : 0];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? rv * cv[j] : 0.f;
         }
-        if (TAIL && gk >= p.K) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = v[j];
+        for (int j = 0; j < 4; ++j) o[j] = kv ? v[j] : 0.f;
       } else {  // L_BLK4
-        const int rlim = IS_A ? p.a_rlim : p.b_rlim;
-        int gr = row0 + r;
-        gr = gr <= rlim - 4 ? gr : rlim - 4;
         f32x4 cv;
-        if (PRO == PA_RANK1 && IS_A) cv = *(const f32x4*)&colv[gr];
+        if (PRO == PA_RANK1 && IS_A) cv = *(const f32x4*)&colv[grow[i]];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int gkj = gk + j;
-          const int kk = TAIL ? (gkj < p.K ? gkj : p.K - 1) : gkj;
-          f32x4 v = *(const f32x4*)&g[(long)kk * sk + gr];
+          const bool kv = !TAIL || (gk + j) < p.K;
+          const float* src = kv ? gk0 + goff[i] + (long)j * sk : g + goff[i] - (long)kin[i] * sk;
+          f32x4 v = *(const f32x4*)src;
           if (PRO == PA_RANK1 && IS_A) {
-            const float rv = rowv[kk];
+            const float rv = rowv[kv ? gk + j : 0];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) v[rr] = v[rr] > 0.f ? rv * cv[rr] : 0.f;
           }
           if (PRO == PB_ONES && !IS_A) {
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) v[rr] = (row0 + r + rr == p.ones_row) ? 1.f : v[rr];
+            for (int rr = 0; rr < 4; ++rr) v[rr] = ((ones[i] >> rr) & 1) ? 1.f : v[rr];
           }
-          if (TAIL && gkj >= p.K) v = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) o[rr * 4 + j] = v[rr];    // transpose: o[row][k]
+          for (int rr = 0; rr < 4; ++rr) o[rr * 4 + j] = kv ? v[rr] : 0.f;    // transpose: o[row][k]
         }
       }
     }
   }
 
-  __device__ inline void store(float* __restrict__ lds, bool k_contig, int tid) const {
+  // split-bf16 staging: hi plane at lds_h, lo plane ROWS*PITCH elements further
+  __device__ static inline void split4(const float* o, bf16x4& h, bf16x4& l) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)o[j]; h[j] = hh; l[j] = (__bf16)(o[j] - (float)hh); }
+  }
+  __device__ inline void store_split(__bf16* __restrict__ lds_h, int tid) const {
+    __bf16* lds_l = lds_h + ROWS * PITCH;
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
-      const int e = tid + i * NT;
-      if (!EXACT && e >= NSLOTS) break;
-      int r, k;
-      slot_rk(e, k_contig, r, k);
+      if (!EXACT && tid + i * NT >= NSLOTS) break;
       const float* o = &reg[i * SLOT_ELEMS];
-      if (LMODE == L_SCALAR) lds[r * PITCH + k] = o[0];
-      else if (LMODE == L_VECK) *(f32x4*)&lds[r * PITCH + k] = (f32x4){o[0], o[1], o[2], o[3]};
+      if (LMODE == L_SCALAR) {
+        const __bf16 hh = (__bf16)o[0];
+        lds_h[loff[i]] = hh; lds_l[loff[i]] = (__bf16)(o[0] - (float)hh);
+      } else if (LMODE == L_VECK) {
+        bf16x4 h, l; split4(o, h, l);
+        *(bf16x4*)(lds_h + loff[i]) = h; *(bf16x4*)(lds_l + loff[i]) = l;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          bf16x4 h, l; split4(o + rr * 4, h, l);
+          *(bf16x4*)(lds_h + loff[i] + rr * PITCH) = h; *(bf16x4*)(lds_l + loff[i] + rr * PITCH) = l;
+        }
+      }
+    }
+  }
+
+  __device__ inline void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      if (!EXACT && tid + i * NT >= NSLOTS) break;
+      const float* o = &reg[i * SLOT_ELEMS];
+      float* d = lds + loff[i];
+      if (LMODE == L_SCALAR) d[0] = o[0];
+      else if (LMODE == L_VECK) *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
       else {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) *(f32x4*)&lds[(r + rr) * PITCH + k] = (f32x4){o[rr * 4], o[rr * 4 + 1], o[rr * 4 + 2], o[rr * 4 + 3]};
+        for (int rr = 0; rr < 4; ++rr) *(f32x4*)(d + rr * PITCH) = (f32x4){o[rr * 4], o[rr * 4 + 1], o[rr * 4 + 2], o[rr * 4 + 3]};
       }
     }
   }
 };
 
-template <class CFG, int LA, int LB, int PA, int PB, int EPI>
+template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC>
 __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
-  constexpr int TM = CFG::TM, TN = CFG::TN, TK = CFG::kTK, NT = CFG::NT, PITCH = CFG::PITCH;
+  constexpr int TM = CFG::TM, TN = CFG::TN, TK = CFG::kTK, NT = CFG::NT;
+  constexpr int PITCH = (PREC == P_F32) ? CFG::PITCH : CFG::PITCH_H;   // LDS row pitch in elements of the plane type
   constexpr int MA = CFG::kMA, NB = CFG::kNB;
+  static_assert(PREC == P_F32 || TK % 32 == 0, "bf16 MFMA consumes 32 k per instruction");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                       // [2][TM][PITCH]
-  float* Bs = smem + 2 * TM * PITCH;      // [2][TN][PITCH]
+  // fp32: As [2][TM][PITCH] floats, Bs [2][TN][PITCH].   split-bf16: As [2][hi,lo][TM][PITCH] bf16, Bs likewise
+  float* As = smem;
+  float* Bs = smem + 2 * TM * PITCH;
+  __bf16* Ah = (__bf16*)smem;
+  __bf16* Bh = Ah + 2 * 2 * TM * PITCH;
 
   const int tid = threadIdx.x;
   const int z = blockIdx.z;
@@ -218,11 +280,12 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 
   TileLoader<TM, TK, NT, PITCH, LA, true, PA> la;
   TileLoader<TN, TK, NT, PITCH, LB, false, PB> lb;
-  const bool a_kc = (p.a_sk == 1), b_kc = (p.b_sk == 1);
+  la.init(p, m0, tid);
+  lb.init(p, n0, tid);
 
   auto load_chunk = [&](int kc) {
-    if (kc < kfull) { la.template load<false>(p, Ag, rowv, colv, m0, kc * TK, tid); lb.template load<false>(p, Bg, nullptr, nullptr, n0, kc * TK, tid); }
-    else { la.template load<true>(p, Ag, rowv, colv, m0, kc * TK, tid); lb.template load<true>(p, Bg, nullptr, nullptr, n0, kc * TK, tid); }
+    if (kc < kfull) { la.template load<false>(p, Ag, rowv, colv, kc * TK, tid); lb.template load<false>(p, Bg, nullptr, nullptr, kc * TK, tid); }
+    else { la.template load<true>(p, Ag, rowv, colv, kc * TK, tid); lb.template load<true>(p, Bg, nullptr, nullptr, kc * TK, tid); }
   };
 
   const int wave = tid >> 6, lane = tid & 63;
@@ -236,81 +299,137 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  auto store_chunk = [&](int buf) {
+    if (PREC == P_F32) { la.store(As + buf * TM * PITCH, tid); lb.store(Bs + buf * TN * PITCH, tid); }
+    else { la.store_split(Ah + buf * 2 * TM * PITCH, tid); lb.store_split(Bh + buf * 2 * TN * PITCH, tid); }
+  };
   if (kc_begin < kc_end) {
     load_chunk(kc_begin);
-    la.store(As, a_kc, tid);
-    lb.store(Bs, b_kc, tid);
+    store_chunk(0);
   }
   __syncthreads();
   for (int kc = kc_begin; kc < kc_end; ++kc) {
     const int buf = (kc - kc_begin) & 1;
     const bool more = kc + 1 < kc_end;
     if (more) load_chunk(kc + 1);
-    const float* as = As + buf * TM * PITCH;
-    const float* bs = Bs + buf * TN * PITCH;
+    if (PREC == P_F32) {
+      const float* as = As + buf * TM * PITCH;
+      const float* bs = Bs + buf * TN * PITCH;
 #pragma unroll
-    for (int kk = 0; kk < TK; kk += 16) {
-      f32x4 fa[MA], fb[NB];
+      for (int kk = 0; kk < TK; kk += 16) {
+        f32x4 fa[MA], fb[NB];
 #pragma unroll
-      for (int a = 0; a < MA; ++a) fa[a] = *(const f32x4*)&as[(wrow0 + a * 16 + li) * PITCH + kk + 4 * lq];
+        for (int a = 0; a < MA; ++a) fa[a] = *(const f32x4*)&as[(wrow0 + a * 16 + li) * PITCH + kk + 4 * lq];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) fb[b] = *(const f32x4*)&bs[(wcol0 + b * 16 + li) * PITCH + kk + 4 * lq];
+        for (int b = 0; b < NB; ++b) fb[b] = *(const f32x4*)&bs[(wcol0 + b * 16 + li) * PITCH + kk + 4 * lq];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int a = 0; a < MA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][s], fa[a][s], acc[a][b], 0, 0, 0);   // transposed tile: D[n][m]
+      }
+    } else {
+      // lane (li, lq) supplies 8 consecutive k (8*lq ..) of row li for both operands of v_mfma_f32_16x16x32_bf16
+      const __bf16* ah = Ah + buf * 2 * TM * PITCH;
+      const __bf16* al = ah + TM * PITCH;
+      const __bf16* bh = Bh + buf * 2 * TN * PITCH;
+      const __bf16* bl = bh + TN * PITCH;
+#pragma unroll
+      for (int kk = 0; kk < TK; kk += 32) {
+        bf16x8 fah[MA], fal[MA], fbh[NB], fbl[NB];
+#pragma unroll
+        for (int a = 0; a < MA; ++a) {
+          const int o = (wrow0 + a * 16 + li) * PITCH + kk + 8 * lq;
+          fah[a] = *(const bf16x8*)&ah[o]; fal[a] = *(const bf16x8*)&al[o];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int o = (wcol0 + b * 16 + li) * PITCH + kk + 8 * lq;
+          fbh[b] = *(const bf16x8*)&bh[o]; fbl[b] = *(const bf16x8*)&bl[o];
+        }
 #pragma unroll
         for (int a = 0; a < MA; ++a)
 #pragma unroll
-          for (int b = 0; b < NB; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a][s], fb[b][s], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < NB; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbl[b], fah[a], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fal[a], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fah[a], acc[a][b], 0, 0, 0);
+          }
+      }
     }
-    if (more) { la.store(As + (buf ^ 1) * TM * PITCH, a_kc, tid); lb.store(Bs + (buf ^ 1) * TN * PITCH, b_kc, tid); }
+    if (more) store_chunk(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane (li, lq) holds C[row = 4*lq + reg][col = li] of each 16x16 block ----
+  // ---- epilogue.  The MFMA was issued with the operands swapped (W-tile as A, X-tile as B), so the 16x16 block
+  // lives transposed in the accumulators: lane (li, lq) holds C[m = li][n = 4*lq + reg], i.e. four CONSECUTIVE
+  // output columns of one row -> one 16-byte store (and 16-byte bias / mask loads) per block instead of four
+  // dword stores. ----
   float* Cg = p.C + z0 * p.c_s0 + z1 * p.c_s1 + (long)ks * p.c_ks;
   const float* __restrict__ bias = p.bias.at(z0, z1);
   const float* __restrict__ aux = p.aux.at(z0, z1);
   float* bo = (EPI == E_WGRAD && p.bias_out) ? p.bias_out + z0 * p.bo_s0 + z1 * p.bo_s1 + (long)ks * p.bo_ks : nullptr;
+  const bool vec_ok = (p.c_sn == 1) && ((p.c_sr & 3) == 0) && ((((uintptr_t)Cg) & 15) == 0) &&
+                      (EPI != E_MASK || (((p.aux_sr & 3) == 0) && ((((uintptr_t)aux) & 15) == 0))) &&
+                      ((EPI != E_BIAS && EPI != E_BIAS_RELU) || ((((uintptr_t)bias) & 15) == 0));
 #pragma unroll
-  for (int a = 0; a < MA; ++a)
+  for (int a = 0; a < MA; ++a) {
+    const int m = m0 + wrow0 + a * 16 + li;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int n = n0 + wcol0 + b * 16 + li;
-      const bool n_ok = n < p.N;
-      float bv = 0.f;
-      if (EPI == E_BIAS || EPI == E_BIAS_RELU) bv = bias[n_ok ? n : 0];
+      const int nb = n0 + wcol0 + b * 16 + 4 * lq;
+      if (m >= p.M || nb >= p.N) continue;
+      f32x4 v = acc[a][b];
+      const int nlim = (EPI == E_WGRAD) ? p.ones_row : p.N;      // columns [nb, nb+4) that go to C
+      if (vec_ok && nb + 4 <= nlim) {
+        if (EPI == E_BIAS || EPI == E_BIAS_RELU) { const f32x4 bv = *(const f32x4*)&bias[nb]; v += bv; }
+        if (EPI == E_BIAS_RELU) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wrow0 + a * 16 + 4 * lq + r;
-        if (!(n_ok && m < p.M)) continue;
-        float v = acc[a][b][r];
-        if (EPI == E_BIAS) v += bv;
-        if (EPI == E_BIAS_RELU) { v += bv; v = v > 0.f ? v : 0.f; }
-        if (EPI == E_MASK) v = aux[(long)m * p.aux_sr + n] > 0.f ? v : 0.f;
-        if (EPI == E_WGRAD) {
-          if (n < p.ones_row) Cg[(long)m * p.c_sr + (long)n * p.c_sn] = v;
-          else if (n == p.ones_row && bo) bo[m] = v;
-        } else {
-          Cg[(long)m * p.c_sr + (long)n * p.c_sn] = v;
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+        if (EPI == E_MASK) {
+          const f32x4 hv = *(const f32x4*)&aux[(long)m * p.aux_sr + nb];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = hv[r] > 0.f ? v[r] : 0.f;
+        }
+        *(f32x4*)&Cg[(long)m * p.c_sr + nb] = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + r;
+          if (n >= p.N) continue;
+          float x = v[r];
+          if (EPI == E_BIAS) x += bias[n];
+          if (EPI == E_BIAS_RELU) { x += bias[n]; x = x > 0.f ? x : 0.f; }
+          if (EPI == E_MASK) x = aux[(long)m * p.aux_sr + n] > 0.f ? x : 0.f;
+          if (EPI == E_WGRAD) {
+            if (n < p.ones_row) Cg[(long)m * p.c_sr + (long)n * p.c_sn] = x;
+            else if (n == p.ones_row && bo) bo[m] = x;
+          } else {
+            Cg[(long)m * p.c_sr + (long)n * p.c_sn] = x;
+          }
         }
       }
     }
+  }
 }
 
 // tile configurations
-typedef GemmCfg<1, 4, 4, 4, 32> CfgBig;    // 64 x 256 : big forward / dgrad (full hidden width per workgroup)
+typedef GemmCfg<2, 4, 2, 4, 32> CfgBig;    // 64 x 256, 8 waves (two per SIMD): big forward / dgrad
 typedef GemmCfg<2, 2, 2, 2, 32> CfgMid;    // 64 x 64  : wgrad tiles with split-K
 typedef GemmCfg<1, 4, 1, 1, 64> CfgSmall;  // 16 x 64  : batch-sized (256-row) phases, many workgroups
 typedef GemmCfg<4, 1, 1, 1, 32> CfgTall;   // 64 x 16  : narrow outputs (heads, action-gradient columns)
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_AUTO = -1 };
+typedef GemmCfg<2, 2, 4, 4, 32> CfgSq;     // 128 x 128: many-row forward/dgrad (several runs) and square wgrad tiles
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_AUTO = -1 };
 
-template <class CFG, int LA, int LB, int PA, int PB, int EPI>
+template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   const int tiles = ((p.M + CFG::TM - 1) / CFG::TM) * ((p.N + CFG::TN - 1) / CFG::TN);
   dim3 grid(tiles, p.ksplit, nz), block(CFG::NT);
-  const size_t lds = CFG::LDS_FLOATS * sizeof(float);
-  auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI>;
+  const size_t lds = CFG::lds_bytes(PREC);
+  auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI, PREC>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // one flag per instantiation
     if (!raised) {
@@ -323,14 +442,14 @@ static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   return hipGetLastError();
 }
 
-// heuristic tile choice when cfg == CFG_AUTO
-static inline int pick_cfg(int M, int N, int K) {
+// heuristic tile choice when cfg == CFG_AUTO (measured with tools/gemm_sweep.py on MI355X)
+static inline int pick_cfg(int M, int N, int K, int nz) {
   if (N <= 16) return CFG_TALL;
-  if (M >= 2048 && N >= 128) return CFG_BIG;
+  if (M >= 2048 && N >= 128) return ((long)M * nz >= 40000) ? CFG_SQ : CFG_BIG;   // few rows: 8-wave 64x256 fills the CUs
   if (M <= 32) return CFG_SMALL;
-  // long reductions (wgrad over thousands of rows) get 64x64 tiles + split-K; batch-sized products get
-  // many small workgroups instead
-  return (K >= 1024) ? CFG_MID : CFG_SMALL;
+  // long reductions (wgrad over thousands of rows): square tiles + split-K; batch-sized products: many small workgroups
+  if (K >= 1024) return (M >= 128 && N >= 128) ? CFG_SQ : CFG_MID;
+  return CFG_SMALL;
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -343,19 +462,25 @@ static inline int pick_loader(const ZPtr& z, long sr, long sk, int K, bool k_pad
   return L_SCALAR;
 }
 
-template <class CFG, int PA, int PB, int EPI>
+template <class CFG, int PA, int PB, int EPI, int PREC>
 static inline hipError_t launch_cfg(const GemmP& p, int la, int lb, int nz, hipStream_t st) {
   // supported loader pairs; anything else falls back to the scalar loaders
-  if (la == L_VECK && lb == L_VECK) return launch_inst<CFG, L_VECK, L_VECK, PA, PB, EPI>(p, nz, st);
-  if (la == L_VECK && lb == L_BLK4) return launch_inst<CFG, L_VECK, L_BLK4, PA, PB, EPI>(p, nz, st);
-  if (la == L_BLK4 && lb == L_BLK4) return launch_inst<CFG, L_BLK4, L_BLK4, PA, PB, EPI>(p, nz, st);
-  if (la == L_VECK) return launch_inst<CFG, L_VECK, L_SCALAR, PA, PB, EPI>(p, nz, st);
-  return launch_inst<CFG, L_SCALAR, L_SCALAR, PA, PB, EPI>(p, nz, st);
+  if (la == L_VECK && lb == L_VECK) return launch_inst<CFG, L_VECK, L_VECK, PA, PB, EPI, PREC>(p, nz, st);
+  if (la == L_VECK && lb == L_BLK4) return launch_inst<CFG, L_VECK, L_BLK4, PA, PB, EPI, PREC>(p, nz, st);
+  if (la == L_BLK4 && lb == L_BLK4) return launch_inst<CFG, L_BLK4, L_BLK4, PA, PB, EPI, PREC>(p, nz, st);
+  if (la == L_VECK) return launch_inst<CFG, L_VECK, L_SCALAR, PA, PB, EPI, PREC>(p, nz, st);
+  return launch_inst<CFG, L_SCALAR, L_SCALAR, PA, PB, EPI, PREC>(p, nz, st);
+}
+template <class CFG, int PA, int PB, int EPI>
+static inline hipError_t launch_cfg_prec(const GemmP& p, int la, int lb, int nz, hipStream_t st, int prec) {
+  if (prec == P_BF16X3) return launch_cfg<CFG, PA, PB, EPI, P_BF16X3>(p, la, lb, nz, st);
+  return launch_cfg<CFG, PA, PB, EPI, P_F32>(p, la, lb, nz, st);
 }
 
 template <int PA, int PB, int EPI>
-static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_t st, bool a_kpad = false, bool force_scalar = false) {
-  if (cfg == CFG_AUTO) cfg = pick_cfg(p.M, p.N, p.K);
+static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_t st, bool a_kpad = false, bool force_scalar = false,
+                                     int prec = P_F32) {
+  if (cfg == CFG_AUTO) cfg = pick_cfg(p.M, p.N, p.K, nz);
   int la = L_SCALAR, lb = L_SCALAR;
   if (!force_scalar) {
     la = pick_loader(p.A, p.a_sr, p.a_sk, p.K, a_kpad, p.a_rlim);
@@ -366,10 +491,38 @@ static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_
     }
   }
   switch (cfg) {
-    case CFG_BIG: return launch_cfg<CfgBig, PA, PB, EPI>(p, la, lb, nz, st);
-    case CFG_MID: return launch_cfg<CfgMid, PA, PB, EPI>(p, la, lb, nz, st);
-    case CFG_SMALL: return launch_cfg<CfgSmall, PA, PB, EPI>(p, la, lb, nz, st);
-    default: return launch_cfg<CfgTall, PA, PB, EPI>(p, la, lb, nz, st);
+    case CFG_BIG: return launch_cfg_prec<CfgBig, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    case CFG_MID: return launch_cfg_prec<CfgMid, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    case CFG_SMALL: return launch_cfg_prec<CfgSmall, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    case CFG_SQ: return launch_cfg_prec<CfgSq, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    default: return launch_cfg_prec<CfgTall, PA, PB, EPI>(p, la, lb, nz, st, prec);
+  }
+}
+
+// ---- tuning tap (orl_debug_gemm_time): the three hot kernel kinds on the main + two extra tile shapes ----
+typedef GemmCfg<1, 4, 4, 4, 32> CfgT7;    // 64 x 256, 4 waves
+typedef GemmCfg<2, 2, 2, 4, 32> CfgT11;   // 64 x 128
+template <class CFG, int PREC>
+static inline hipError_t launch_tune_kind_p(int kind, const GemmP& p, int nz, hipStream_t st) {
+  if (kind == 0) return launch_inst<CFG, L_VECK, L_VECK, PA_PLAIN, PB_PLAIN, E_BIAS_RELU, PREC>(p, nz, st);
+  if (kind == 1) return launch_inst<CFG, L_VECK, L_BLK4, PA_RANK1, PB_PLAIN, E_MASK, PREC>(p, nz, st);
+  return launch_inst<CFG, L_BLK4, L_BLK4, PA_RANK1, PB_ONES, E_WGRAD, PREC>(p, nz, st);
+}
+template <class CFG>
+static inline hipError_t launch_tune_kind(int kind, const GemmP& p, int nz, hipStream_t st, int prec) {
+  if (prec == P_BF16X3) return launch_tune_kind_p<CFG, P_BF16X3>(kind, p, nz, st);
+  return launch_tune_kind_p<CFG, P_F32>(kind, p, nz, st);
+}
+static inline hipError_t launch_tune(int cfg_in, int kind, const GemmP& p, int nz, hipStream_t st) {
+  const int prec = (cfg_in & 32) ? P_BF16X3 : P_F32;      // bit 5 selects the split-bf16 multiply
+  switch (cfg_in & 31) {
+    case 0: return launch_tune_kind<CfgBig>(kind, p, nz, st, prec);
+    case 1: return launch_tune_kind<CfgMid>(kind, p, nz, st, prec);
+    case 2: return launch_tune_kind<CfgSmall>(kind, p, nz, st, prec);
+    case 3: return launch_tune_kind<CfgTall>(kind, p, nz, st, prec);
+    case 4: return launch_tune_kind<CfgSq>(kind, p, nz, st, prec);
+    case 7: return launch_tune_kind<CfgT7>(kind, p, nz, st, prec);
+    default: return launch_tune_kind<CfgT11>(kind, p, nz, st, prec);
   }
 }
 

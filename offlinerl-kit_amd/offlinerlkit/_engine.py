@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
     "orl_set_lr", "orl_reset_optimizers", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
     "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
-    "orl_debug_read", "orl_debug_gemm", "orl_profile_enable", "orl_profile_query",
+    "orl_debug_read", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
 ]
 
 
@@ -127,6 +127,7 @@ def load_library(path: Optional[str] = None):
     lib.orl_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64]
     lib.orl_debug_read.restype = C.c_int64
     lib.orl_debug_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_int, C.c_int]
+    lib.orl_debug_gemm_time.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_float)]
     lib.orl_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.orl_profile_query.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double)]

@@ -12,14 +12,14 @@ pytestmark = pytest.mark.gpu
 NETS = {"actor": 0, "critic1": 1, "critic2": 2, "critic1_old": 3, "critic2_old": 4}
 
 
-def make_engine(case, n_runs=1):
+def make_engine(case, n_runs=1, precision=0):
     from offlinerlkit import _engine
     cfg, st, batches, noises = cql_oracle_setup(case)
     c = synth.CQL_CASES[case]
     over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs,
                 num_repeat_actions=c["N"], target_entropy=cfg["target_entropy"], auto_alpha=int(cfg["auto_alpha"]),
                 alpha=cfg["alpha"], max_q_backup=int(cfg["max_q_backup"]), deterministic_backup=int(cfg["deterministic_backup"]),
-                with_lagrange=int(cfg["with_lagrange"]))
+                with_lagrange=int(cfg["with_lagrange"]), precision=precision)
     eng = _engine.Engine(_engine.default_config("cql", **over))
     for r in range(n_runs):
         for nm, nid in NETS.items():
@@ -121,4 +121,25 @@ def test_cql_learn_n_device_sampling_runs_and_is_finite():
     assert np.isfinite(m2).all()
     # the two runs draw different indices/noise -> different losses
     assert not np.array_equal(m[0], m[1])
+    eng.close()
+
+
+@pytest.mark.parametrize("case", ["cql_tiny", "cql_tiny_lagrange", "cql_halfcheetah", "cql_halfcheetah_h3"])
+def test_cql_split_bf16_precision_meets_the_gate(case):
+    """precision=1 (3 bf16 MFMA products per multiply, fp32 accumulate) against the reference fixtures at the SAME
+    gate as fp32: losses 1e-4 relative, Q-values 1e-4 of scale, over the teacher-forced window."""
+    eng, cfg, st, batches, noises = make_engine(case, precision=1)
+    g = load_golden(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    worst = 0.0
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        m = eng.step(lead(b), lead(noise_list(n)))[0]
+        e = rel_err(m, g[f"step{k}/losses"], floor=1e-2)
+        worst = max(worst, e)
+        assert e < 1e-4, (case, k, m, g[f"step{k}/losses"])
+        if k == 0:
+            for tap, gkey in (("q1", "step0/c1_q"), ("q2", "step0/c2_q"), ("q1a", "step0/c1_qa"), ("target_q", "step0/target_q")):
+                if gkey in g.files:
+                    assert scale_err(eng.debug_read(0, tap), g[gkey]) < 1e-4, (tap, scale_err(eng.debug_read(0, tap), g[gkey]))
+    print(case, "worst loss rel err (split-bf16):", worst)
     eng.close()
