@@ -333,6 +333,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   memset(&p, 0, sizeof(p));
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
   p.a_sr = 1; p.a_sk = dy.m.pitch;
+  if (out == 1 && dy.m.pitch == 1 && !dy.rank1) p.a_sr = 4;   // a [1 x M] row vector: k-contiguous, any row stride -> vector loads
   if (dy.rank1) {
     p.a_trans = 1;
     p.rowv = {dy.rowv.p, dy.rowv.rs, dy.rowv.cs};
@@ -341,8 +342,8 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   p.B = {X.p, X.rs, X.cs};
   p.b_sr = 1; p.b_sk = X.pitch;
   p.a_rlim = dy.m.pitch & ~3; p.b_rlim = X.pitch & ~3;
-  p.ones_row = in_rows;
-  p.M = out; p.N = in_rows + (with_bias ? 1 : 0); p.K = M;
+  p.ones_row = 1 << 30;
+  p.M = out; p.N = in_rows; p.K = M;
   p.nz1 = nr.nz1; p.ksplit = ksplit;
   const long g_rs = (long)max_slab * P_train;
   float* g = grads + nr.g_off + (long)slab0 * P_train;
@@ -351,8 +352,8 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   p.c_s0 = g_rs; p.c_s1 = l.w_ms[layer]; p.c_ks = P_train;
   if (with_bias) { p.bias_out = g + l.b_off[layer]; p.bo_s0 = g_rs; p.bo_s1 = l.b_ms[layer]; p.bo_ks = P_train; }
   const int nz = R * nr.nz1;
-  if (dy.rank1) return run_gemm<PA_RANK1, PB_ONES, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
-  return run_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
+  if (dy.rank1) return run_gemm<PA_RANK1, PB_PLAIN, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
+  return run_gemm<PA_PLAIN, PB_PLAIN, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
 }
 
 int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div) {
@@ -423,7 +424,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   std::vector<int> ks(L + 1, 1);
   std::string t = tag;
   if (want_w) {
-    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i) + 1, M, nz, e->max_slab / 2);
+    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->max_slab / 2);
     if (e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
   }
   DY cur;
@@ -1040,10 +1041,10 @@ int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const
     else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 0; err = launch_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(cfg, p, 1, st, false, fs, precision); }
   } else {
     p.A = {dA, 0, 0}; p.a_sr = 1; p.a_sk = M; p.B = {dB, 0, 0}; p.b_sr = 1; p.b_sk = N;
-    p.M = M; p.N = N + 1; p.K = K; p.c_sr = N; p.ones_row = N;
+    p.M = M; p.N = N; p.K = K; p.c_sr = N; p.ones_row = 1 << 30;
     p.bias_out = dC + (long)M * N; p.bo_ks = nC;
-    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs, precision);
-    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_ONES, E_WGRAD>(cfg, p, 1, st, false, fs, precision); }
+    if (mode == 2) err = launch_gemm<PA_PLAIN, PB_PLAIN, E_WGRAD>(cfg, p, 1, st, false, fs, precision);
+    else { p.rowv = {d0, 0, 0}; p.colv = {d1, 0, 0}; p.a_trans = 1; err = launch_gemm<PA_RANK1, PB_PLAIN, E_WGRAD>(cfg, p, 1, st, false, fs, precision); }
   }
   if (err != hipSuccess) return fail(std::string("debug gemm launch: ") + hipGetErrorString(err));
   ORL_HIP(hipDeviceSynchronize());
@@ -1098,8 +1099,8 @@ int orl_debug_gemm_time(int cfg, int kind, int M, int N, int K, int nz, int kspl
       p.a_sr = K; p.a_sk = 1; p.b_sr = 1; p.b_sk = N; p.b_rlim = N & ~3; p.M = M; p.N = N; p.K = K; p.c_sr = N; p.a_trans = 0;
       err = launch_tune(cfg, 1, p, nz, st);
     } else {
-      p.a_sr = 1; p.a_sk = M; p.b_sr = 1; p.b_sk = N; p.a_rlim = M & ~3; p.b_rlim = N & ~3; p.M = M; p.N = N + 1; p.K = K; p.c_sr = N;
-      p.ones_row = N; p.a_trans = 1; p.c_ks = (long)M * (N + 1); p.c_s1 = nC; p.bias_out = dC + (long)M * N; p.bo_s1 = nC; p.bo_ks = (long)M * (N + 1);
+      p.a_sr = 1; p.a_sk = M; p.b_sr = 1; p.b_sk = N; p.a_rlim = M & ~3; p.b_rlim = N & ~3; p.M = M; p.N = N; p.K = K; p.c_sr = N;
+      p.ones_row = 1 << 30; p.a_trans = 1; p.c_ks = (long)M * (N + 1); p.c_s1 = nC; p.bias_out = dC + (long)M * N; p.bo_s1 = nC; p.bo_ks = (long)M * (N + 1);
       err = launch_tune(cfg, 2, p, nz, st);
     }
     if (err != hipSuccess) return fail(std::string("gemm_time launch: ") + hipGetErrorString(err));

@@ -73,7 +73,7 @@ struct GemmP {
   ZPtr bias;         // E_BIAS / E_BIAS_RELU: bias[n]
   ZPtr aux;          // E_MASK: C = aux[m*aux_sr + n] > 0 ? acc : 0
   long aux_sr;
-  // E_WGRAD: n < ones_row -> C[m*c_sr + n*c_sn];  n == ones_row -> bias_out[m]   (same slab / z strides as C)
+  // E_WGRAD: C[m*c_sr + n*c_sn] = dW ; bias_out[m] = sum_k A[m][k] (bias gradient; same slab / z strides as C) or null
   float* bias_out;
   long bo_s0, bo_s1, bo_ks;
 };
@@ -299,6 +299,13 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // E_WGRAD with bias_out: the bias gradient db[m] = sum_k A[m][k] is accumulated by the first column tile with one
+  // extra MFMA per row block whose other operand is all ones (no extra B column, so N stays tile-aligned)
+  const bool want_bias = (EPI == E_WGRAD) && (p.bias_out != nullptr) && (tn == 0) && (wn == 0);
+  f32x4 accb[MA];
+#pragma unroll
+  for (int a = 0; a < MA; ++a) accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
   auto store_chunk = [&](int buf) {
     if (PREC == P_F32) { la.store(As + buf * TM * PITCH, tid); lb.store(Bs + buf * TN * PITCH, tid); }
     else { la.store_split(Ah + buf * 2 * TM * PITCH, tid); lb.store_split(Bh + buf * 2 * TN * PITCH, tid); }
@@ -329,6 +336,12 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
               acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[b][s], fa[a][s], acc[a][b], 0, 0, 0);   // transposed tile: D[n][m]
+        if (EPI == E_WGRAD && want_bias) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int a = 0; a < MA; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, fa[a][s], accb[a], 0, 0, 0);
+        }
       }
     } else {
       // lane (li, lq) supplies 8 consecutive k (8*lq ..) of row li for both operands of v_mfma_f32_16x16x32_bf16
@@ -357,6 +370,16 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fal[a], acc[a][b], 0, 0, 0);
             acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fah[a], acc[a][b], 0, 0, 0);
           }
+        if (EPI == E_WGRAD && want_bias) {
+          bf16x8 one;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) one[j] = (__bf16)1.0f;
+#pragma unroll
+          for (int a = 0; a < MA; ++a) {
+            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fal[a], accb[a], 0, 0, 0);
+            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fah[a], accb[a], 0, 0, 0);
+          }
+        }
       }
     }
     if (more) store_chunk(buf ^ 1);
@@ -374,6 +397,13 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const bool vec_ok = (p.c_sn == 1) && ((p.c_sr & 3) == 0) && ((((uintptr_t)Cg) & 15) == 0) &&
                       (EPI != E_MASK || (((p.aux_sr & 3) == 0) && ((((uintptr_t)aux) & 15) == 0))) &&
                       ((EPI != E_BIAS && EPI != E_BIAS_RELU) || ((((uintptr_t)bias) & 15) == 0));
+  if (EPI == E_WGRAD && want_bias && lq == 0) {
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+      const int m = m0 + wrow0 + a * 16 + li;
+      if (m < p.M) bo[m] = accb[a][0];      // every n-row of the ones-block holds the same sum; lane (li, 0) reg 0 = D[0][m]
+    }
+  }
 #pragma unroll
   for (int a = 0; a < MA; ++a) {
     const int m = m0 + wrow0 + a * 16 + li;
@@ -382,7 +412,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
       const int nb = n0 + wcol0 + b * 16 + 4 * lq;
       if (m >= p.M || nb >= p.N) continue;
       f32x4 v = acc[a][b];
-      const int nlim = (EPI == E_WGRAD) ? p.ones_row : p.N;      // columns [nb, nb+4) that go to C
+      const int nlim = p.N;
       if (vec_ok && nb + 4 <= nlim) {
         if (EPI == E_BIAS || EPI == E_BIAS_RELU) { const f32x4 bv = *(const f32x4*)&bias[nb]; v += bv; }
         if (EPI == E_BIAS_RELU) {
@@ -404,12 +434,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
           if (EPI == E_BIAS) x += bias[n];
           if (EPI == E_BIAS_RELU) { x += bias[n]; x = x > 0.f ? x : 0.f; }
           if (EPI == E_MASK) x = aux[(long)m * p.aux_sr + n] > 0.f ? x : 0.f;
-          if (EPI == E_WGRAD) {
-            if (n < p.ones_row) Cg[(long)m * p.c_sr + (long)n * p.c_sn] = x;
-            else if (n == p.ones_row && bo) bo[m] = x;
-          } else {
-            Cg[(long)m * p.c_sr + (long)n * p.c_sn] = x;
-          }
+          Cg[(long)m * p.c_sr + (long)n * p.c_sn] = x;
         }
       }
     }
@@ -506,7 +531,7 @@ template <class CFG, int PREC>
 static inline hipError_t launch_tune_kind_p(int kind, const GemmP& p, int nz, hipStream_t st) {
   if (kind == 0) return launch_inst<CFG, L_VECK, L_VECK, PA_PLAIN, PB_PLAIN, E_BIAS_RELU, PREC>(p, nz, st);
   if (kind == 1) return launch_inst<CFG, L_VECK, L_BLK4, PA_RANK1, PB_PLAIN, E_MASK, PREC>(p, nz, st);
-  return launch_inst<CFG, L_BLK4, L_BLK4, PA_RANK1, PB_ONES, E_WGRAD, PREC>(p, nz, st);
+  return launch_inst<CFG, L_BLK4, L_BLK4, PA_RANK1, PB_PLAIN, E_WGRAD, PREC>(p, nz, st);
 }
 template <class CFG>
 static inline hipError_t launch_tune_kind(int kind, const GemmP& p, int nz, hipStream_t st, int prec) {
