@@ -28,7 +28,10 @@ for p in (ROOT, os.path.join(ROOT, "offlinerl-kit_amd"), os.path.join(ROOT, "tes
         sys.path.insert(0, p)
 
 OBS, ACT, HIDDEN, BATCH, NREP = 17, 6, [256, 256], 256, 10
-PEAK_TFLOPS = {0: 157.3, 1: 2500.0 / 3.0}   # fp32 MFMA dense peak; split-bf16 = 3 bf16 MFMAs per product (MI355X_MICROARCH.md)
+# MI355X_MICROARCH.md: fp32 MFMA dense peak 157.3 TFLOP/s; bf16 MFMA dense peak ~2500 TFLOP/s.  precision=1 spends three
+# bf16 MFMAs per fp32-equivalent product, so its ceiling for ALGORITHMIC flops is 2500/3.
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0 / 3.0}
+DTYPE = {0: "f32 (v_mfma_f32_16x16x4_f32)", 1: "f32 via split-bf16 (3x v_mfma_f32_16x16x32_bf16, fp32 accumulate)"}
 
 
 def mlp_flops_per_row(in_dim, hidden, out_dim):
@@ -81,12 +84,17 @@ def init_weights(eng, run, seed):
     return dict(actor=actor, critic1=c1, critic2=c2)
 
 
-def cpu_baseline(seconds=12.0):
+def cpu_baseline(seconds=14.0):
     """The oracle (numpy port of the reference CQL learn(), parity-pinned in tests/test_oracle_golden.py) timed on
-    this box's host cores on the same synthetic workload."""
+    this box's host cores on the same synthetic workload.  BLAS thread count is swept (1, 8, 16, 32) because OpenBLAS
+    on all cores of a large host is SLOWER on these 256-wide layers; the best setting is reported with its thread count."""
     import synth
     from oracle import cql as ocql
     from helpers import clone_state
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:
+        threadpool_limits = None
     rng = np.random.RandomState(5)
     st = dict(actor=synth.make_tanh_actor(rng, OBS, ACT, HIDDEN), critic1=synth.make_critic(rng, OBS + ACT, HIDDEN),
               critic2=synth.make_critic(rng, OBS + ACT, HIDDEN))
@@ -97,26 +105,33 @@ def cpu_baseline(seconds=12.0):
     ocql.init_opt(st)
     cfg = ocql.default_cfg(OBS, ACT)
     ds = make_dataset(0, 100_000)
-    n, t0 = 0, None
-    while True:
+
+    def one_step():
         idx = np.random.randint(0, 100_000, size=BATCH)          # buffer.py:98
         batch = dict(observations=ds["obs"][idx], actions=ds["act"][idx], next_observations=ds["nobs"][idx],
                      rewards=ds["rew"][idx], terminals=ds["term"][idx])
-        noise = synth.make_cql_noise(rng, BATCH, NREP, ACT)
-        ocql.learn(st, cfg, batch, noise)
-        n += 1
-        if n == 3:
-            t0 = time.perf_counter(); n0 = n       # 3 warm-up steps
-        if t0 is not None and time.perf_counter() - t0 > seconds:
-            break
-    dt = time.perf_counter() - t0
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count()
-    return dict(value=(n - n0) / dt, unit="gradient-steps/s", cores=int(threads), kind="port",
-                sample=f"{n - n0} CQL learn() steps of the numpy oracle (OpenBLAS, {threads} threads, host has {os.cpu_count()} cpus), batch 256, ~{seconds:.0f} s")
+        ocql.learn(st, cfg, batch, synth.make_cql_noise(rng, BATCH, NREP, ACT))
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (1, 8, 16, 32) if t <= ncpu}) if threadpool_limits else [ncpu]
+    best = None
+    per = seconds / max(len(cands), 1)
+    for t in cands:
+        ctx = threadpool_limits(limits=t) if threadpool_limits else None
+        try:
+            one_step(); one_step()
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < per:
+                one_step(); n += 1
+            rate = n / (time.perf_counter() - t0)
+        finally:
+            if ctx is not None:
+                ctx.unregister() if hasattr(ctx, "unregister") else None
+        if best is None or rate > best[0]:
+            best = (rate, t, n)
+    return dict(value=best[0], unit="gradient-steps/s", cores=int(best[1]), kind="port",
+                sample=f"{best[2]} CQL learn() steps (batch 256, ~{per:.0f} s) of the numpy oracle at its best BLAS thread count "
+                       f"({best[1]} of {cands} tried; host has {ncpu} cpus)")
 
 
 def main():
@@ -124,8 +139,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--runs-per-gpu", type=int, default=int(os.environ.get("ORL_RUNS_PER_GPU", "1")))
-    ap.add_argument("--precision", type=int, default=0)
+    ap.add_argument("--runs-per-gpu", type=int, default=int(os.environ.get("ORL_RUNS_PER_GPU", "16")),
+                    help="independent CQL runs (seeds) carried by one engine / GPU; every launch updates all of them")
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split-bf16 MFMA (parity-gated)")
+    ap.add_argument("--no-single", action="store_true", help="skip the side measurement with ONE run per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--dataset-size", type=int, default=1_000_000)
@@ -136,10 +153,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    backend = os.environ.get("ORL_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 path on one GPU
+    if os.environ.get("ORL_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["ORL_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))     # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+    cdev = "cuda" if backend == "nccl" else "cpu"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); torch.cuda.is_available() is False")
 
@@ -170,11 +194,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # end-of-epoch metric all-gather over RCCL/xGMI (the only collective of the path)
-        mine = torch.tensor(metrics, device="cuda", dtype=torch.float32)
+        mine = torch.tensor(metrics, device=cdev, dtype=torch.float32)
         allm = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allm, mine)
         metrics_all = torch.stack(allm).cpu().numpy()
@@ -185,6 +209,19 @@ def main():
     total_steps = args.steps * R * world
     value = total_steps / dt
     out = None
+    single = None
+    if rank == 0 and not args.no_single and R > 1:
+        # side measurement: the same workload with ONE run on the GPU (latency-bound regime), same precision
+        cfg1 = _engine.default_config("cql", obs_dim=OBS, act_dim=ACT, hidden=HIDDEN, batch_size=BATCH, n_runs=1, device=local_rank,
+                                      precision=args.precision, seed=99, num_repeat_actions=NREP, target_entropy=-float(ACT))
+        e1 = _engine.Engine(cfg1)
+        e1.attach_buffer(buf)
+        init_weights(e1, 0, 12345)
+        e1.learn_n(100)
+        n1 = max(200, args.steps // 2)
+        t1 = time.perf_counter(); e1.learn_n(n1); d1 = time.perf_counter() - t1
+        single = dict(value=n1 / d1, ms_per_step=d1 / n1 * 1e3, runs_per_gpu=1)
+        e1.close()
     if rank == 0:
         flops_step = cql_algorithmic_flops()
         # live per-kernel timing with HIP events on the engine stream (eager launches, not the graph)
@@ -210,13 +247,13 @@ def main():
             "metric": "gradient-steps/sec (CQL, batch=256)", "value": value, "unit": "gradient-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == 0 else "f32 via 3x bf16 MFMA split",
+            "dtype": DTYPE[args.precision],
             "data": "synthetic D4RL-shaped replay buffer (N(0,1) obs, tanh actions), random-init weights",
             "config": {"workload": "CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
                                    "auto-alpha, device sampling+noise, %d run(s)/GPU x %d GPU(s) (independent seeds)" % (R, world),
                        "runs_per_gpu": R, "dataset_transitions": args.dataset_size, "event_ms_per_step": ev_ms / args.steps,
                        "algorithmic_gflop_per_gradient_step": flops_step / 1e9},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "single_run": single,
             "final_metrics_rank0_run0": dict(zip(eng.metric_names, [float(x) for x in metrics[0]])),
         }
         print(json.dumps(out))

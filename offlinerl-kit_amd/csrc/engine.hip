@@ -396,7 +396,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   const int Ln = nr.lay->L;
   std::string t = tag;
   for (int i = 0; i < Ln; ++i)
-    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd").c_str())) return -1;
+    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str())) return -1;
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
 }
 
