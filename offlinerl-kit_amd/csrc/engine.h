@@ -9,6 +9,7 @@
 #include "../../include/orl_engine.h"
 #include "gemm.h"
 #include "kernels.h"
+#include "mlp_fused.h"
 
 namespace orl {
 
@@ -133,6 +134,7 @@ struct Engine {
   bool use_graph = true;
   bool force_scalar = false;   // debug: disable the vector loaders
   int loss_nblk = 1;
+  bool use_fused = false;      // fused multi-layer forward kernel (csrc/mlp_fused.h), opt-in with ORL_FUSED=1
 
   ~Engine();
   int init(const orl_config& c);

@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -393,8 +394,32 @@ int Engine::assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int
 }
 
 int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag) {
-  const int Ln = nr.lay->L;
+  const NetLayout& l = *nr.lay;
+  const int Ln = l.L;
   std::string t = tag;
+  // fused path: all hidden layers + tail in one launch (csrc/mlp_fused.h)
+  bool elig = use_fused && !force_scalar && !l.ens && l.out_dim <= 16 && X.pitch >= ((l.in_dim + 3) & ~3) && aligned16(X.p) &&
+              (X.rs & 3) == 0 && (X.cs & 3) == 0 && (X.pitch & 3) == 0;
+  for (int i = 0; i < Ln && elig; ++i) elig = (l.H[i] == 256) && aligned16(hs[i].p) && (hs[i].pitch & 3) == 0 && (hs[i].rs & 3) == 0 && (hs[i].cs & 3) == 0;
+  if (elig) {
+    FusedFwdP p;
+    memset(&p, 0, sizeof(p));
+    p.X = {X.p, X.rs, X.cs}; p.x_sr = X.pitch; p.in_dim = l.in_dim; p.in_pad = (l.in_dim + 3) & ~3;
+    p.M = M; p.L = Ln; p.H = 256; p.out_dim = l.out_dim;
+    p.Wt = {nr.base, nr.rs, l.w_ms[0]};
+    double flops = 0;
+    for (int i = 0; i <= Ln; ++i) { p.w_off[i] = l.w_off[i]; p.b_off[i] = l.b_off[i]; flops += 2.0 * M * l.layer_in(i) * l.layer_out(i); }
+    for (int i = 0; i < Ln; ++i) { p.hs[i] = hs[i].p; p.h_s0[i] = hs[i].rs; p.h_s1[i] = hs[i].cs; p.h_pitch[i] = hs[i].pitch; }
+    p.out = out.p; p.o_s0 = out.rs; p.o_s1 = out.cs; p.o_pitch = out.pitch;
+    p.nz1 = nr.nz1;
+    const int nz = R * nr.nz1;
+    prof_begin((t + ".fused_fwd").c_str(), flops * nz);
+    hipError_t err = launch_fused_fwd(p, nz, cfg.precision, stream);
+    prof_end();
+    if (err == hipSuccess) return 0;
+    if (err != hipErrorNotSupported) return fail(std::string("fused forward launch ") + tag + ": " + hipGetErrorString(err));
+    if (prof_on) prof.pop_back();
+  }
   for (int i = 0; i < Ln; ++i)
     if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str())) return -1;
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
@@ -525,6 +550,7 @@ int Engine::init(const orl_config& c) {
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
+  use_fused = getenv("ORL_FUSED") != nullptr;   // opt-in: measured slower than the layer-wise kernels
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {

@@ -15,6 +15,8 @@
 //   L_VECK   k-contiguous, 16 B aligned : one global_load_dwordx4 per 4 k, one ds_write_b128
 //   L_BLK4   row-contiguous, aligned    : a 4(row) x 4(k) block per slot: four dwordx4 loads along the rows,
 //                                         transposed in registers, four ds_write_b128 along k
+//   L_VECKU  k-contiguous, unaligned    : same 4-k slots and wide LDS stores, but four dword loads (e.g. a
+//                                         first-layer weight matrix whose rows are 23 floats long)
 //   L_SCALAR anything else              : one dword per slot, clamped address + select (no divergent branches)
 // Rows beyond M/N are read from a clamped (valid) row and discarded by the epilogue; only the K tail is
 // zero-filled.  The multiply is v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD on gfx950): lane
@@ -43,7 +45,7 @@ enum { P_F32 = 0, P_BF16X3 = 1 };
 enum { PA_PLAIN = 0, PA_RANK1 = 1 };                                   // prologue on A elements
 enum { PB_PLAIN = 0, PB_ONES = 1 };                                    // prologue on B elements
 enum { E_PLAIN = 0, E_BIAS = 1, E_BIAS_RELU = 2, E_MASK = 3, E_WGRAD = 4 };
-enum { L_SCALAR = 0, L_VECK = 1, L_BLK4 = 2 };                         // operand loaders
+enum { L_SCALAR = 0, L_VECK = 1, L_BLK4 = 2, L_VECKU = 3 };            // operand loaders
 
 struct ZPtr {        // base + z0 * s0 + z1 * s1 (element strides)
   const float* p;
@@ -96,7 +98,7 @@ struct GemmCfg {
 template <int ROWS, int TK, int NT, int PITCH, int LMODE, bool IS_A, int PRO>
 struct TileLoader {
   static constexpr int ELEMS = ROWS * TK;
-  static constexpr int SLOT_ELEMS = (LMODE == L_SCALAR) ? 1 : (LMODE == L_VECK ? 4 : 16);
+  static constexpr int SLOT_ELEMS = (LMODE == L_SCALAR) ? 1 : ((LMODE == L_VECK || LMODE == L_VECKU) ? 4 : 16);
   static constexpr int NSLOTS = ELEMS / SLOT_ELEMS;
   static constexpr int PER_THREAD = (NSLOTS + NT - 1) / NT;
   static constexpr bool EXACT = (NSLOTS % NT) == 0;
@@ -110,7 +112,7 @@ struct TileLoader {
   long sk_;
 
   __device__ static inline void slot_rk(int e, bool k_contig, int& r, int& k) {
-    if (LMODE == L_VECK) { constexpr int Q = TK / 4; k = 4 * (e % Q); r = e / Q; }
+    if (LMODE == L_VECK || LMODE == L_VECKU) { constexpr int Q = TK / 4; k = 4 * (e % Q); r = e / Q; }
     else if (LMODE == L_BLK4) { constexpr int Q = ROWS / 4; r = 4 * (e % Q); k = 4 * (e / Q); }
     else if (k_contig) { k = e % TK; r = e / TK; }
     else { r = e % ROWS; k = e / ROWS; }
@@ -177,6 +179,18 @@ struct TileLoader {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = kv ? v[j] : 0.f;
+      } else if (LMODE == L_VECKU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool kv = !TAIL || (gk + j) < p.K;
+          float v = kv ? gk0[goff[i] + j] : 0.f;
+          if (PRO == PA_RANK1 && IS_A) {
+            const int kk = kv ? gk + j : 0;
+            const int mm = p.a_trans ? kk : grow[i], nn = p.a_trans ? grow[i] : kk;
+            v = (kv && v > 0.f) ? rowv[mm] * colv[nn] : 0.f;
+          }
+          o[j] = v;
+        }
       } else {  // L_BLK4
         f32x4 cv;
         if (PRO == PA_RANK1 && IS_A) cv = *(const f32x4*)&colv[grow[i]];
@@ -215,7 +229,7 @@ struct TileLoader {
       if (LMODE == L_SCALAR) {
         const __bf16 hh = (__bf16)o[0];
         lds_h[loff[i]] = hh; lds_l[loff[i]] = (__bf16)(o[0] - (float)hh);
-      } else if (LMODE == L_VECK) {
+      } else if (LMODE == L_VECK || LMODE == L_VECKU) {
         bf16x4 h, l; split4(o, h, l);
         *(bf16x4*)(lds_h + loff[i]) = h; *(bf16x4*)(lds_l + loff[i]) = l;
       } else {
@@ -235,7 +249,7 @@ struct TileLoader {
       const float* o = &reg[i * SLOT_ELEMS];
       float* d = lds + loff[i];
       if (LMODE == L_SCALAR) d[0] = o[0];
-      else if (LMODE == L_VECK) *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
+      else if (LMODE == L_VECK || LMODE == L_VECKU) *(f32x4*)d = (f32x4){o[0], o[1], o[2], o[3]};
       else {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) *(f32x4*)(d + rr * PITCH) = (f32x4){o[rr * 4], o[rr * 4 + 1], o[rr * 4 + 2], o[rr * 4 + 3]};
@@ -481,6 +495,7 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 // loader choice per operand from strides / alignment.  k_pad_ok: rows are zero-padded up to a multiple of 4 in k
 static inline int pick_loader(const ZPtr& z, long sr, long sk, int K, bool k_pad_ok, int rlim) {
+  if (sk == 1 && (!aligned16(z.p) || (z.s0 & 3) || (z.s1 & 3) || (sr & 3) || !((K & 3) == 0 || k_pad_ok))) return L_VECKU;
   if (!aligned16(z.p) || (z.s0 & 3) || (z.s1 & 3)) return L_SCALAR;
   if (sk == 1 && (sr & 3) == 0 && ((K & 3) == 0 || k_pad_ok)) return L_VECK;
   if (sr == 1 && (sk & 3) == 0 && rlim >= 4 && (rlim & 3) == 0) return L_BLK4;
@@ -493,6 +508,7 @@ static inline hipError_t launch_cfg(const GemmP& p, int la, int lb, int nz, hipS
   if (la == L_VECK && lb == L_VECK) return launch_inst<CFG, L_VECK, L_VECK, PA, PB, EPI, PREC>(p, nz, st);
   if (la == L_VECK && lb == L_BLK4) return launch_inst<CFG, L_VECK, L_BLK4, PA, PB, EPI, PREC>(p, nz, st);
   if (la == L_BLK4 && lb == L_BLK4) return launch_inst<CFG, L_BLK4, L_BLK4, PA, PB, EPI, PREC>(p, nz, st);
+  if (la == L_VECK && lb == L_VECKU) return launch_inst<CFG, L_VECK, L_VECKU, PA, PB, EPI, PREC>(p, nz, st);
   if (la == L_VECK) return launch_inst<CFG, L_VECK, L_SCALAR, PA, PB, EPI, PREC>(p, nz, st);
   return launch_inst<CFG, L_SCALAR, L_SCALAR, PA, PB, EPI, PREC>(p, nz, st);
 }
