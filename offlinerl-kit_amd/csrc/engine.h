@@ -150,7 +150,7 @@ struct Engine {
                  int in_row0 = 0, int in_rows = -1);
   int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag);
   int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                   const char* tag, int in_row0 = 0, int in_rows = -1);
+                   const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr);
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
   int polyak(int target_net, int src_net, int nnets);
   void prof_begin(const char* name, double flops);

@@ -325,7 +325,7 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
 }
 
 int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                         const char* tag, int in_row0, int in_rows) {
+                         const char* tag, int in_row0, int in_rows, bool* fuse_tail) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
@@ -353,6 +353,14 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   p.c_s0 = g_rs; p.c_s1 = l.w_ms[layer]; p.c_ks = P_train;
   if (with_bias) { p.bias_out = g + l.b_off[layer]; p.bo_s0 = g_rs; p.bo_s1 = l.b_ms[layer]; p.bo_ks = P_train; }
   const int nz = R * nr.nz1;
+  if (fuse_tail) {
+    // the rank-1 kernel streams h and dq anyway: let it also emit the tail layer's dw / db (same split-K slabs)
+    *fuse_tail = dy.rank1 && rank1_wgrad_is_fast(p, force_scalar);
+    if (*fuse_tail) {
+      p.tail_w_out = g + l.w_off[l.L]; p.tail_b_out = g + l.b_off[l.L];
+      p.tw_s0 = g_rs; p.tw_s1 = l.w_ms[l.L]; p.tb_s1 = l.b_ms[l.L];
+    }
+  }
   if (dy.rank1) return run_gemm<PA_RANK1, PB_PLAIN, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
   return run_gemm<PA_PLAIN, PB_PLAIN, E_WGRAD>(this, CFG_AUTO, p, nz, tag);
 }
@@ -450,7 +458,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   std::string t = tag;
   if (want_w) {
     for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->max_slab / 2);
-    if (e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
+    if (!rank1 && e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
   }
   DY cur;
   if (rank1) cur = DY::virt(hs[L - 1], dTail);
@@ -461,7 +469,13 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   for (int i = L - 1; i >= 0; --i) {
     const Mat& xin = (i == 0) ? X : hs[i - 1];
     if (want_w) {
-      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str())) return -1;
+      bool fused = false;
+      const bool top = rank1 && (i == L - 1);
+      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr)) return -1;
+      if (top) {
+        if (fused) ks[L] = ks[i];           // the tail gradients were written into the same split-K slabs
+        else if (e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
+      }
     }
     if (i > 0) {
       if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], (t + ".dgrad" + std::to_string(i)).c_str())) return -1;

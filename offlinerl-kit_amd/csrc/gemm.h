@@ -78,6 +78,11 @@ struct GemmP {
   // E_WGRAD: C[m*c_sr + n*c_sn] = dW ; bias_out[m] = sum_k A[m][k] (bias gradient; same slab / z strides as C) or null
   float* bias_out;
   long bo_s0, bo_s1, bo_ks;
+  // PA_RANK1 wgrad through the L_BLK4 loader: the kernel already streams h (raw activations) and dq (rowv), so it can
+  // also produce the TAIL layer's gradients dw_tail[n'] = sum_m dq[m] h[m][n'] and db_tail = sum_m dq[m] (first column
+  // tile only); null = not requested.  Same slab / z strides as C.
+  float* tail_w_out; float* tail_b_out;
+  long tw_s0, tw_s1, tb_s1;
 };
 
 template <int WM, int WN, int MA, int NB, int TK>
@@ -110,6 +115,8 @@ struct TileLoader {
   int grow[PER_THREAD];     // clamped global row (rank-1 prologue) 
   int ones[PER_THREAD];     // PB_ONES: bit rr set -> row (r + rr) is the virtual ones row
   long sk_;
+  float tacc[(LMODE == L_BLK4 && IS_A && PRO == PA_RANK1) ? PER_THREAD * 4 : 1];   // fused tail-weight gradient partials
+  float bacc;
 
   __device__ static inline void slot_rk(int e, bool k_contig, int& r, int& k) {
     if (LMODE == L_VECK || LMODE == L_VECKU) { constexpr int Q = TK / 4; k = 4 * (e % Q); r = e / Q; }
@@ -144,6 +151,8 @@ struct TileLoader {
       }
       ones[i] = om;
     }
+    bacc = 0.f;
+    for (int i = 0; i < (int)(sizeof(tacc) / sizeof(float)); ++i) tacc[i] = 0.f;
   }
 
   // TAIL = false: the whole chunk [k0, k0+TK) is inside K (no k checks)
@@ -201,6 +210,11 @@ struct TileLoader {
           f32x4 v = *(const f32x4*)src;
           if (PRO == PA_RANK1 && IS_A) {
             const float rv = rowv[kv ? gk + j : 0];
+            if (p.tail_w_out && kv) {       // uniform branch: raw v = post-ReLU activation (>= 0)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) tacc[i * 4 + rr] += rv * v[rr];
+              if (((tid + i * NT) % (ROWS / 4)) == 0) bacc += rv;
+            }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) v[rr] = v[rr] > 0.f ? rv * cv[rr] : 0.f;
           }
@@ -411,6 +425,40 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const bool vec_ok = (p.c_sn == 1) && ((p.c_sr & 3) == 0) && ((((uintptr_t)Cg) & 15) == 0) &&
                       (EPI != E_MASK || (((p.aux_sr & 3) == 0) && ((((uintptr_t)aux) & 15) == 0))) &&
                       ((EPI != E_BIAS && EPI != E_BIAS_RELU) || ((((uintptr_t)bias) & 15) == 0));
+  if (EPI == E_WGRAD && PA == PA_RANK1 && LA == L_BLK4) {
+    if (p.tail_w_out && tn == 0) {
+      // deterministic reduction of the per-thread partials: sred[k-slot][row], summed in k-slot order
+      constexpr int KQ = TK / 4, Q = TM / 4;
+      float* sred = smem;                                   // the staging tiles are dead after the last barrier
+      float* sb = smem + KQ * TM;
+#pragma unroll
+      for (int i = 0; i < decltype(la)::PER_THREAD; ++i) {
+        const int e = tid + i * NT;
+        if (e < decltype(la)::NSLOTS) {
+          const int r = 4 * (e % Q), kq = e / Q;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) sred[kq * TM + r + rr] = la.tacc[i * 4 + rr];
+        }
+      }
+      sb[tid] = la.bacc;                                     // zero for threads that own no first-row-block slot
+      __syncthreads();
+      float* tw = p.tail_w_out + z0 * p.tw_s0 + z1 * p.tw_s1 + (long)ks * p.c_ks;
+      for (int r = tid; r < TM; r += NT) {
+        const int m = m0 + r;
+        if (m < p.M) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int kq = 0; kq < KQ; ++kq) sacc += sred[kq * TM + r];
+          tw[m] = sacc;
+        }
+      }
+      if (tm == 0 && tid == 0 && p.tail_b_out) {
+        float sacc = 0.f;
+        for (int t = 0; t < NT; ++t) sacc += sb[t];
+        p.tail_b_out[z0 * p.tw_s0 + z1 * p.tb_s1 + (long)ks * p.c_ks] = sacc;
+      }
+    }
+  }
   if (EPI == E_WGRAD && want_bias && lq == 0) {
 #pragma unroll
     for (int a = 0; a < MA; ++a) {
@@ -500,6 +548,15 @@ static inline int pick_loader(const ZPtr& z, long sr, long sk, int K, bool k_pad
   if (sk == 1 && (sr & 3) == 0 && ((K & 3) == 0 || k_pad_ok)) return L_VECK;
   if (sr == 1 && (sk & 3) == 0 && rlim >= 4 && (rlim & 3) == 0) return L_BLK4;
   return L_SCALAR;
+}
+
+// true when launch_gemm will run a rank-1 wgrad through the (L_BLK4, L_BLK4) loaders, i.e. when the fused
+// tail-gradient outputs of GemmP are honoured
+static inline bool rank1_wgrad_is_fast(const GemmP& p, bool force_scalar) {
+  if (force_scalar || p.a_trans != 1) return false;
+  if (pick_loader(p.A, p.a_sr, p.a_sk, p.K, false, p.a_rlim) != L_BLK4) return false;
+  if (pick_loader(p.B, p.b_sr, p.b_sk, p.K, false, p.b_rlim) != L_BLK4) return false;
+  return aligned16(p.colv.p) && (p.colv.s0 & 3) == 0 && (p.colv.s1 & 3) == 0;
 }
 
 template <class CFG, int PA, int PB, int EPI, int PREC>
