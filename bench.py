@@ -237,8 +237,11 @@ def main():
                 avg_ms = top["total_ms"] / top["launches"]
                 ach = top["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
                 peak = PEAK_TFLOPS[args.precision]
+                gbps = top["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
                 roof = dict(bound="mfma", kernel=top["name"], achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
                             traffic=None, avg_launch_ms=avg_ms, flops_per_launch=top["flops_per_launch"],
+                            # the same launch against the HBM roof (algorithmic bytes: operands read once, result written once)
+                            hbm=dict(bytes_per_launch=top["bytes_per_launch"], achieved=gbps, peak=8000.0, unit="GB/s", frac=gbps / 8000.0),
                             step_frac_of_mlp_gemm_roofline=(value / world) * flops_step / (peak * 1e12),
                             table=[dict(name=t["name"], ms_per_step=t["total_ms"] / args.profile_steps,
                                         launches_per_step=t["launches"] / args.profile_steps) for t in table[:12]])

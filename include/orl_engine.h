@@ -191,7 +191,7 @@ int orl_debug_gemm_time(int cfg, int kind, int M, int N, int K, int nz, int kspl
  * when profiling was enabled with orl_profile_enable(e,1); name copied to `name`. */
 int orl_profile_enable(orl_engine* e, int on);
 int orl_profile_query(orl_engine* e, int idx, char* name, int name_cap, double* total_ms, int64_t* launches,
-                      double* flops_per_launch);
+                      double* flops_per_launch, double* bytes_per_launch);
 
 #ifdef __cplusplus
 }

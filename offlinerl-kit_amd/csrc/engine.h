@@ -75,6 +75,7 @@ struct NetRef {
 struct ProfEntry {
   std::string name;
   double flops;
+  double bytes = 0;   // algorithmic HBM bytes of the launch (operands read once + results written once)
   hipEvent_t a, b;
 };
 
@@ -153,7 +154,7 @@ struct Engine {
                    const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr);
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
   int polyak(int target_net, int src_net, int nnets);
-  void prof_begin(const char* name, double flops);
+  void prof_begin(const char* name, double flops, double bytes = 0);
   void prof_end();
   int assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep);
   int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);

@@ -204,7 +204,7 @@ NetRef Engine::net_ref(int net, int members) const {
   return r;
 }
 
-void Engine::prof_begin(const char* name, double flops) {
+void Engine::prof_begin(const char* name, double flops, double bytes) {
   if (!prof_on) return;
   while (ev_pool.size() < ev_used + 2) {
     hipEvent_t e;
@@ -214,6 +214,7 @@ void Engine::prof_begin(const char* name, double flops) {
   ProfEntry pe;
   pe.name = name;
   pe.flops = flops;
+  pe.bytes = bytes;
   pe.a = ev_pool[ev_used++];
   pe.b = ev_pool[ev_used++];
   hipEventRecord(pe.a, stream);
@@ -235,7 +236,10 @@ void Engine::prof_end() {
 template <int PA, int PB, int EPI>
 static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag, bool a_kpad = false) {
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
-  e->prof_begin(tag, flops);
+  // algorithmic bytes: each operand read once, the result written once (split-K: one slab per split), mask read once
+  const double bytes = 4.0 * nz * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (EPI == E_WGRAD ? p.ksplit : 1) +
+                                   (EPI == E_MASK ? (double)p.M * p.N : 0.0));
+  e->prof_begin(tag, flops, bytes);
   hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar, e->cfg.precision);
   e->prof_end();
   if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
@@ -1016,15 +1020,16 @@ int64_t orl_debug_read(orl_engine* h, int run, const char* name, float* host, in
 }
 
 int orl_profile_enable(orl_engine* h, int on) { h->e.prof_on = on != 0; return 0; }
-int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops_per_launch) {
+int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* total_ms, int64_t* launches, double* flops_per_launch,
+                      double* bytes_per_launch) {
   Engine& e = h->e;
   if (hipStreamSynchronize(e.stream) != hipSuccess) return fail("sync");
-  std::map<std::string, std::tuple<double, int64_t, double>> agg;
+  std::map<std::string, std::tuple<double, int64_t, double, double>> agg;
   for (auto& p : e.prof) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
     auto& a = agg[p.name];
-    std::get<0>(a) += ms; std::get<1>(a) += 1; std::get<2>(a) = p.flops;
+    std::get<0>(a) += ms; std::get<1>(a) += 1; std::get<2>(a) = p.flops; std::get<3>(a) = p.bytes;
   }
   std::vector<std::pair<double, std::string>> order;
   for (auto& kv : agg) order.push_back({-std::get<0>(kv.second), kv.first});
@@ -1033,6 +1038,7 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
   const auto& a = agg[order[idx].second];
   snprintf(name, name_cap, "%s", order[idx].second.c_str());
   *total_ms = std::get<0>(a); *launches = std::get<1>(a); *flops_per_launch = std::get<2>(a);
+  if (bytes_per_launch) *bytes_per_launch = std::get<3>(a);
   return 0;
 }
 

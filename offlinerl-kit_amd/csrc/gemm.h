@@ -288,10 +288,20 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const int tid = threadIdx.x;
   const int z = blockIdx.z;
   const int z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  // XCD-aware tile mapping (MI355X: 8 XCDs with private L2s; workgroups are dealt round-robin over them by linear
+  // id, and gridDim.x is padded to a multiple of 8 so the XCD of a block is blockIdx.x % 8 for every z).  Logical work
+  // items (tile, k-split) are numbered tile-fastest and each XCD takes a CONTIGUOUS range of them, so the tiles that
+  // share an operand panel (all column tiles of one row tile; all tiles of one k-split in wgrad) hit the same L2
+  // instead of each fetching the panel from HBM.  Only speed depends on the placement, never correctness.
   const int tiles_n = (p.N + TN - 1) / TN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int tiles = ((p.M + TM - 1) / TM) * tiles_n;
+  const int total = tiles * p.ksplit;
+  const int per_xcd = gridDim.x >> 3;
+  const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (item >= total) return;
+  const int ks = item / tiles, tile = item - ks * tiles;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
-  const int ks = blockIdx.y;
 
   const float* __restrict__ Ag = p.A.at(z0, z1);
   const float* __restrict__ Bg = p.B.at(z0, z1);
@@ -514,7 +524,7 @@ enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_AU
 template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   const int tiles = ((p.M + CFG::TM - 1) / CFG::TM) * ((p.N + CFG::TN - 1) / CFG::TN);
-  dim3 grid(tiles, p.ksplit, nz), block(CFG::NT);
+  dim3 grid((tiles * p.ksplit + 7) & ~7, 1, nz), block(CFG::NT);     // padded to the 8 XCDs (see the kernel's tile mapping)
   const size_t lds = CFG::lds_bytes(PREC);
   auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI, PREC>;
   if (lds > 64 * 1024) {

@@ -130,7 +130,7 @@ def load_library(path: Optional[str] = None):
     lib.orl_debug_gemm_time.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_float)]
     lib.orl_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.orl_profile_query.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
-                                      C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+                                      C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if path is None:
         _lib = lib
     return lib
@@ -305,11 +305,12 @@ class Engine:
         i = 0
         while True:
             name = C.create_string_buffer(128)
-            tot, cnt, fl = C.c_double(), C.c_int64(), C.c_double()
-            rc = self.lib.orl_profile_query(self._h, i, name, 128, C.byref(tot), C.byref(cnt), C.byref(fl))
+            tot, cnt, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            rc = self.lib.orl_profile_query(self._h, i, name, 128, C.byref(tot), C.byref(cnt), C.byref(fl), C.byref(by))
             if rc != 0:
                 break
-            rows.append(dict(name=name.value.decode(), total_ms=tot.value, launches=cnt.value, flops_per_launch=fl.value))
+            rows.append(dict(name=name.value.decode(), total_ms=tot.value, launches=cnt.value, flops_per_launch=fl.value,
+                             bytes_per_launch=by.value))
             i += 1
         return rows
 
