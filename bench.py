@@ -145,6 +145,7 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the side measurement with ONE run per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--profile-dump", default="", help="write the full per-launch-tag timing table (HIP events) to this file")
     ap.add_argument("--dataset-size", type=int, default=1_000_000)
     args = ap.parse_args()
 
@@ -231,6 +232,18 @@ def main():
             eng.learn_n(args.profile_steps)
             table = eng.profile_table()
             eng.profile_enable(False)
+            if args.profile_dump:
+                with open(args.profile_dump, "w") as f:
+                    tot = sum(t["total_ms"] for t in table)
+                    f.write("# %d profiled steps, %d runs/GPU, precision %d; eager launches timed with HIP events on the engine stream\n"
+                            % (args.profile_steps, R, args.precision))
+                    f.write("%-40s %9s %10s %10s %7s %9s %9s\n" % ("tag", "launches", "us/launch", "us/step", "%", "TFLOP/s", "GB/s"))
+                    for t in table:
+                        us = t["total_ms"] / t["launches"] * 1e3
+                        f.write("%-40s %9.1f %10.1f %10.1f %7.1f %9.1f %9.1f\n" % (
+                            t["name"], t["launches"] / args.profile_steps, us, t["total_ms"] / args.profile_steps * 1e3,
+                            100 * t["total_ms"] / tot, t["flops_per_launch"] / us / 1e6, t["bytes_per_launch"] / us / 1e3))
+                    f.write("%-40s %9s %10s %10.1f\n" % ("total", "", "", tot / args.profile_steps * 1e3))
             gemms = [t for t in table if t["flops_per_launch"] > 0]
             if gemms:
                 top = max(gemms, key=lambda t: t["total_ms"])
