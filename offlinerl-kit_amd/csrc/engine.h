@@ -103,7 +103,8 @@ struct Engine {
   float* adam_m = nullptr;
   float* adam_v = nullptr;
   float* grads = nullptr;      // [R][max_slab][P_train]
-  int max_slab = 64;
+  int max_slab = 128;          // split-K slabs per parameter (the fused layer-0 weight gradient writes one per row tile)
+  int ksplit_cap = 32;         // cap of the split-K factor chosen for a stand-alone wgrad launch
   RunScalars* scalars = nullptr;
   Hyper* hyper = nullptr;
   Hyper hyper_host;
@@ -149,7 +150,8 @@ struct Engine {
   // launch helpers (enqueue on stream)
   int linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH, const char* tag,
                  int in_row0 = 0, int in_rows = -1);
-  int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag);
+  int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag,
+                   const Mat* w0_X = nullptr, bool store_dx = true, int* w0_slabs = nullptr);
   int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
                    const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr);
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);

@@ -239,7 +239,9 @@ static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag,
   // algorithmic bytes: each operand read once, the result written once (split-K: one slab per split), mask read once
   const double bytes = 4.0 * nz * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (EPI == E_WGRAD ? p.ksplit : 1) +
                                    (EPI == E_MASK ? (double)p.M * p.N : 0.0));
-  e->prof_begin(tag, flops, bytes);
+  double bytes_adj = bytes;
+  if (EPI == E_MASK && p.w0_out) bytes_adj += 4.0 * nz * ((double)p.M * p.w0_xsr - (p.C ? 0.0 : (double)p.M * p.N));
+  e->prof_begin(tag, flops + (EPI == E_MASK && p.w0_out ? 2.0 * p.M * (double)p.N * (p.w0_in + 1) * nz : 0.0), bytes_adj);
   hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar, e->cfg.precision);
   e->prof_end();
   if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
@@ -282,7 +284,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
 }
 
 int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH,
-                         const Mat& dX, const char* tag) {
+                         const Mat& dX, const char* tag, const Mat* w0_X, bool store_dx, int* w0_slabs) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   GemmP p;
@@ -301,6 +303,19 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   p.nz1 = nr.nz1; p.ksplit = 1;
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
   const int nz = R * nr.nz1;
+  if (w0_slabs) *w0_slabs = 0;
+  if (w0_X && w0_slabs && maskH && layer == 1 && col0 == 0 && !l.ens && !force_scalar) {
+    // fuse the layer-0 weight / bias gradient into this launch's epilogue (one slab per row tile)
+    const int slabs = w0_fused_slabs(p, nz, l.layer_in(0), w0_X->pitch, w0_X->p, w0_X->rs, w0_X->cs, max_slab);
+    if (slabs > 0) {
+      float* g = grads + nr.g_off;
+      p.w0_x = {w0_X->p, w0_X->rs, w0_X->cs}; p.w0_xsr = w0_X->pitch; p.w0_in = l.layer_in(0);
+      p.w0_out = g + l.w_off[0]; p.w0_bias = g + l.b_off[0];
+      p.w0_s0 = (long)max_slab * P_train; p.w0_s1 = l.w_ms[0]; p.w0_bs1 = l.b_ms[0]; p.w0_ks = P_train; p.w0_sr = l.layer_in(0);
+      if (!store_dx) p.C = nullptr;
+      *w0_slabs = slabs;
+    }
+  }
   if (dy.rank1) {
     if (maskH) return run_gemm<PA_RANK1, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
     return run_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
@@ -461,10 +476,11 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   std::vector<int> ks(L + 1, 1);
   std::string t = tag;
   if (want_w) {
-    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->max_slab / 2);
+    for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->ksplit_cap);
     if (!rank1 && e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
   }
   DY cur;
+  bool w0_done = false;
   if (rank1) cur = DY::virt(hs[L - 1], dTail);
   else {
     if (e->linear_dgrad(DY::plain(dTail), M, nr, L, 0, l.layer_in(L), &hs[L - 1], dz[L - 1], (t + ".dgrad_tail").c_str())) return -1;
@@ -472,7 +488,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   }
   for (int i = L - 1; i >= 0; --i) {
     const Mat& xin = (i == 0) ? X : hs[i - 1];
-    if (want_w) {
+    if (want_w && !(i == 0 && w0_done)) {
       bool fused = false;
       const bool top = rank1 && (i == L - 1);
       if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr)) return -1;
@@ -482,7 +498,11 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
       }
     }
     if (i > 0) {
-      if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], (t + ".dgrad" + std::to_string(i)).c_str())) return -1;
+      // the dgrad that produces dz0 can also produce dW0 / db0 (and then dz0 is only stored when dX is wanted)
+      int w0_slabs = 0;
+      if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], (t + ".dgrad" + std::to_string(i)).c_str(),
+                          (want_w && i == 1) ? &X : nullptr, want_dx, &w0_slabs)) return -1;
+      if (w0_slabs > 0) { w0_done = true; ks[0] = w0_slabs; }
       cur = DY::plain(dz[i - 1]);
     } else if (want_dx) {
       if (e->linear_dgrad(cur, M, nr, 0, dx_col0, dx_ncols, nullptr, *dX, (t + ".dgrad_x").c_str())) return -1;

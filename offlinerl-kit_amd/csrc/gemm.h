@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 namespace orl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -83,7 +85,15 @@ struct GemmP {
   // tile only); null = not requested.  Same slab / z strides as C.
   float* tail_w_out; float* tail_b_out;
   long tw_s0, tw_s1, tb_s1;
+  // E_MASK with w0_out != null (dgrad of hidden layer 1, tiles whose waves own 32 columns each): the masked tile
+  // dz0 = C never has to reach HBM for the weight gradient of layer 0 -- the epilogue also produces this row tile's
+  // contribution  dW0[n][c] = sum_r dz0[r][n] * X[r][c],  db0[n] = sum_r dz0[r][n]  (exact fp32 MFMA) into split-K slab
+  // `row tile index`; Adam sums the slabs.  C == null then skips the store of dz0 altogether.
+  ZPtr w0_x; long w0_xsr; int w0_in;
+  float* w0_out; float* w0_bias; long w0_s0, w0_s1, w0_bs1, w0_ks, w0_sr;
 };
+
+enum { W0_XP = 28 };     // LDS pitch of the X tile staged by the fused layer-0 weight gradient (floats)
 
 template <int WM, int WN, int MA, int NB, int TK>
 struct GemmCfg {
@@ -507,7 +517,9 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   // and let every wave move whole row segments: 64 lanes x 16 B = two 512-B runs (TN = 128) per instruction.
   constexpr int CP = TN + 4;                                   // LDS pitch of the staged C tile (floats)
   constexpr bool LDS_EPI_FITS = (size_t)TM * CP * sizeof(float) <= CFG::lds_bytes(PREC) && (NT % (TN / 4)) == 0;
-  if (LDS_EPI_FITS && vec_ok && (p.N & 3) == 0) {             // uniform per workgroup
+  constexpr bool W0_CAP = (EPI == E_MASK) && (TN / (NT / 64) == 32) && (TM % 16 == 0);
+  const bool w0 = W0_CAP && (p.w0_out != nullptr);             // uniform; the host only asks when the LDS path below is taken
+  if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
     float* cs = smem;
     constexpr int C4 = TN / 4, RPP = NT / C4, NPASS = (TM + RPP - 1) / RPP;   // float4 columns per row, rows per pass
     const int c4 = tid % C4, r0 = tid / C4;
@@ -523,6 +535,22 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
         hv[i] = *(const f32x4*)&aux[(long)m * p.aux_sr + (n_ok ? n : 0)];
       }
     }
+    // fused layer-0 weight gradient: this thread's pieces of the X tile [TM][W0_XP], fetched now for the same reason
+    constexpr int XQ = W0_XP / 4, XPT = W0_CAP ? (TM * XQ + NT - 1) / NT : 1;
+    f32x4 xv[XPT];
+    if (W0_CAP && w0) {
+      const float* __restrict__ xg = p.w0_x.at(z0, z1);
+      const int xq = (int)(p.w0_xsr >> 2);                     // float4 per X row in memory (<= XQ)
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int e = tid + i * NT, r = e / XQ, q = e - r * XQ;
+        int m = m0 + r; m = m < p.M ? m : p.M - 1;
+        xv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < xq && e < TM * XQ) xv[i] = *(const f32x4*)&xg[(long)m * p.w0_xsr + 4 * q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (4 * q + j == p.w0_in) xv[i][j] = 1.0f;     // ones column -> bias gradient
+      }
+    }
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (EPI == E_BIAS || EPI == E_BIAS_RELU) bv = *(const f32x4*)&bias[n_ok ? n : 0];
     if (EPI == E_WGRAD && PA == PA_RANK1 && LA == L_BLK4) __syncthreads();   // the tail-gradient reduction above used smem
@@ -531,6 +559,14 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         *(f32x4*)&cs[(wrow0 + a * 16 + li) * CP + wcol0 + b * 16 + 4 * lq] = acc[a][b];
+    if (W0_CAP && w0) {
+      float* xs = cs + TM * CP;                                // X tile behind the C tile
+#pragma unroll
+      for (int i = 0; i < XPT; ++i) {
+        const int e = tid + i * NT;
+        if (e < TM * XQ) *(f32x4*)&xs[(e / XQ) * W0_XP + 4 * (e % XQ)] = xv[i];
+      }
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NPASS; ++i) {
@@ -547,8 +583,58 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = hv[i][j] > 0.f ? v[j] : 0.f;
         }
-        if (n_ok && m < p.M) *(f32x4*)&Cg[(long)m * p.c_sr + n] = v;
+        if (n_ok && m < p.M && (!W0_CAP || p.C != nullptr)) *(f32x4*)&Cg[(long)m * p.c_sr + n] = v;
+        if (W0_CAP && w0) {                                    // masked values (zero beyond M / N) back into the staged tile
+          if (!(n_ok && m < p.M)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)&cs[r * CP + 4 * c4] = v;
+        }
       }
+    }
+    if (W0_CAP && w0) {
+      const float* xs = cs + TM * CP;
+      __syncthreads();
+      // wave w owns columns [32w, 32w+32) of the tile: D[n][c] = sum_r cs[r][n] * xs[r][c], 2 x 2 blocks of 16 x 16
+      f32x4 d[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) d[nb][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int ncol0 = 32 * wave;
+      const int c1 = (16 + li) < W0_XP ? 16 + li : W0_XP - 1;   // columns >= W0_XP are never stored
+#pragma unroll 2
+      for (int k0 = 0; k0 < TM; k0 += 16) {
+        float av[2][4], bw[2][4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const int r = k0 + 4 * lq + sidx;
+          av[0][sidx] = cs[r * CP + ncol0 + li];
+          av[1][sidx] = cs[r * CP + ncol0 + 16 + li];
+          bw[0][sidx] = xs[r * W0_XP + li];
+          bw[1][sidx] = xs[r * W0_XP + c1];
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              d[nb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[nb][sidx], bw[cb][sidx], d[nb][cb], 0, 0, 0);
+      }
+      // lane (li, lq) holds D[n = 4*lq + reg][c = li] of each block
+      float* wo = p.w0_out + z0 * p.w0_s0 + z1 * p.w0_s1 + (long)tm * p.w0_ks;
+      float* bo0 = p.w0_bias + z0 * p.w0_s0 + z1 * p.w0_bs1 + (long)tm * p.w0_ks;
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int nn = n0 + ncol0 + 16 * nb + 4 * lq + rg, c = 16 * cb + li;
+            if (nn < p.N) {
+              if (c < p.w0_in) wo[(long)nn * p.w0_sr + c] = d[nb][cb][rg];
+              else if (c == p.w0_in) bo0[nn] = d[nb][cb][rg];
+            }
+          }
     }
   } else {
 #pragma unroll
@@ -605,7 +691,8 @@ template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   const int tiles = ((p.M + CFG::TM - 1) / CFG::TM) * ((p.N + CFG::TN - 1) / CFG::TN);
   dim3 grid((tiles * p.ksplit + 7) & ~7, 1, nz), block(CFG::NT);     // padded to the 8 XCDs (see the kernel's tile mapping)
-  const size_t lds = CFG::lds_bytes(PREC);
+  size_t lds = CFG::lds_bytes(PREC);
+  if (EPI == E_MASK && p.w0_out) lds = std::max(lds, sizeof(float) * ((size_t)CFG::TM * (CFG::TN + 4) + (size_t)CFG::TM * W0_XP));
   auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI, PREC>;
   if (lds > 64 * 1024) {
     static bool raised = false;   // one flag per instantiation
@@ -630,6 +717,19 @@ static inline int pick_cfg(int M, int N, int K, int nz) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Can the E_MASK dgrad launch (M x N x K, nz problems) also produce the layer-0 weight gradient in its epilogue (GemmP::w0_*)?
+// Returns the number of split-K slabs it would write (= row tiles), 0 if not.  Mirrors the kernel's conditions.
+static inline int w0_fused_slabs(const GemmP& p, int nz, int in0, long x_pitch, const void* x_ptr, long x_s0, long x_s1, int max_slab) {
+  const int cfg = pick_cfg(p.M, p.N, p.K, nz);
+  const int TM = cfg == CFG_SQ ? CfgSq::TM : (cfg == CFG_BIG ? CfgBig::TM : 0);
+  if (!TM) return 0;                                                       // tiles whose waves own 32 columns each
+  if (in0 + 1 > W0_XP || in0 >= x_pitch || x_pitch > W0_XP || (x_pitch & 3) || !aligned16(x_ptr) || (x_s0 & 3) || (x_s1 & 3)) return 0;
+  if ((p.N & 3) || (p.aux_sr & 3) || !aligned16(p.aux.p) || (p.aux.s0 & 3) || (p.aux.s1 & 3)) return 0;   // LDS epilogue path
+  if (p.C && (!aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1)) return 0;
+  const int tiles_m = (p.M + TM - 1) / TM;
+  return tiles_m <= max_slab ? tiles_m : 0;
+}
 
 // loader choice per operand from strides / alignment.  k_pad_ok: rows are zero-padded up to a multiple of 4 in k
 static inline int pick_loader(const ZPtr& z, long sr, long sk, int K, bool k_pad_ok, int rlim) {

@@ -545,8 +545,20 @@ __global__ void k_adam(AdamP p) {
   const float* g = p.g + z0 * p.g_s0 + z1 * p.g_s1 + i;
   int nslab = p.seg_nslab[0];
   for (int k = 1; k < p.nseg; ++k) if (i >= p.seg_end[k - 1]) nslab = p.seg_nslab[k];
-  float gs = 0.f;
-  for (int s = 0; s < nslab; ++s) gs += g[(long)s * p.g_ks];
+  // split-K slabs summed in a fixed order with eight independent partial sums (many slabs: the loads stay in flight)
+  float gs;
+  if (nslab == 1) gs = g[0];
+  else {
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] += g[(long)(s + j) * p.g_ks];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (s + j < nslab) q[j] += g[(long)(s + j) * p.g_ks];
+    gs = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+  }
   const long o = z0 * p.p_s0 + z1 * p.p_s1 + i;
   float m = p.m[o], v = p.v[o], w = p.params[o];
   m = m + (gs - m) * (1.0f - p.b1);

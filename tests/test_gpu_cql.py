@@ -105,6 +105,36 @@ def test_cql_multi_run_independent():
     eng.close(); eng1.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+def test_cql_many_runs_full_size_matches_oracle(precision):
+    """Four full-size runs per engine: the run-batched launches then take the 128x128 tile path and the dgrad epilogue
+    that also produces the layer-0 weight gradient (one split-K slab per row tile).  Every run gets identical inputs and
+    must follow the oracle; parameters are compared with the same statistical criterion as the single-run test."""
+    from oracle import cql as ocql
+    case = "cql_halfcheetah"
+    R = 4
+    eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    try:
+        keys = eng.metric_names
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            res, aux = ocql.learn(st, cfg, b, n)
+            m = eng.step(lead(b, R), lead(noise_list(n), R))
+            ora = np.array([res[x] for x in keys])
+            for r in range(R):
+                assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (k, r, m[r], ora)
+        for r in ((0, R - 1) if precision == 0 else ()):        # split-bf16 is gated on losses / Q-values only
+            for nm in ("critic1", "critic2", "actor"):
+                got = eng.get_net(r, NETS[nm])
+                for pn, v in got.items():
+                    d = np.abs(v - st[nm][pn])
+                    tol = 4e-6 * 3 + 1e-4 * np.abs(st[nm][pn]).max()
+                    assert d.mean() < 1e-6 * 3, (r, nm, pn, d.mean())
+                    assert (d > tol).mean() < 2e-3, (r, nm, pn, (d > tol).mean())
+                    assert d.max() < 2 * 3e-4 * 3, (r, nm, pn, d.max())
+    finally:
+        eng.close()
+
+
 def test_cql_learn_n_device_sampling_runs_and_is_finite():
     from offlinerlkit import _engine
     case = "cql_tiny"

@@ -50,11 +50,9 @@ int main(int argc, char** argv) {
   typedef GemmCfg<2, 4, 2, 4, 32> C_2424;
   typedef GemmCfg<4, 4, 2, 4, 32> C_4424;
   typedef GemmCfg<1, 4, 4, 4, 32> C_1444;
-#ifdef ORL_LAB_STAMPS
-  unsigned long long* dst; CK(hipMalloc(&dst, 8 * 16 * 128)); CK(hipMemset(dst, 0, 8 * 16 * 128));
-  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &dst, sizeof(dst)));
-  auto dump = [&](const char* name) {
-    CK(hipDeviceSynchronize());
+  FWD(C_2244, P_BF16X3) FWD(C_2444, P_BF16X3) FWD(C_4424, P_BF16X3) FWD(C_2442, P_BF16X3)
+  DGR(C_2244, P_BF16X3) DGR(C_2444, P_BF16X3) DGR(C_4424, P_BF16X3) DGR(C_2442, P_BF16X3)
+  CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(16 * 128); CK(hipMemcpy(st.data(), dst, 8 * 16 * 128, hipMemcpyDeviceToHost));
     printf("%s stamps (cycles from kernel-entry stamp; idx: 1 init done, 2 first chunk staged, 3 loads(k+1) issued, 4 mfma done, 5 store done, 6 barrier done, 7.. second iter, 12 loop done, 13 epilogue done)\n", name);
     for (int b : {0, 1, 8, 60, 100, 127}) { printf("  blk %3d:", b); for (int i = 1; i < 14; ++i) printf(" %6lld", st[b * 16 + i] ? (long long)(st[b * 16 + i] - st[b * 16]) : -1LL); printf("\n"); }
