@@ -258,7 +258,7 @@ struct DY {
 };
 
 int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH,
-                       const char* tag, int in_row0, int in_rows) {
+                       const char* tag, int in_row0, int in_rows, const Mat* tail_out, bool* tail_fused) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
@@ -275,8 +275,37 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   p.bias = {nr.base + l.b_off[layer], nr.rs, l.b_ms[layer]};
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
   const int nz = R * nr.nz1;
+  int cfg = pick_cfg(p.M, p.N, p.K, nz);
+  if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
+  if (tail_fused) *tail_fused = false;
+  int tq_parts = 0;
+  if (tail_out && tail_fused && epi == E_BIAS_RELU && layer == l.L - 1 && l.out_dim == 1 && !force_scalar && ws.count("tq_scratch")) {
+    const float* tw = nr.base + l.w_off[l.L];
+    tq_parts = tq_fused_parts(cfg, p, tw, nr.rs, l.w_ms[l.L]);
+    const Mat& sc = ws.at("tq_scratch");
+    if (tq_parts >= 1 && (long)(tq_parts - 1) * M <= sc.cs && nr.nz1 <= tq_scratch_nets) {
+      p.tq_w = {tw, nr.rs, l.w_ms[l.L]};
+      p.tq_b = {nr.base + l.b_off[l.L], nr.rs, l.b_ms[l.L]};
+      p.tq_out = tail_out->p; p.tq_s0 = tail_out->rs; p.tq_s1 = tail_out->cs; p.tq_sm = tail_out->pitch;
+      p.tq_part = sc.p; p.tq_ps0 = sc.rs; p.tq_ps1 = sc.cs; p.tq_ts = M;
+      *tail_fused = true;
+    } else tq_parts = 0;
+  }
+  if (tq_parts >= 1) {
+    if (run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, cfg, p, nz, tag, a_kpad)) return -1;
+    if (tq_parts > 1) {
+      TailAddP t;
+      t.out = p.tq_out; t.o_s0 = p.tq_s0; t.o_s1 = p.tq_s1; t.o_sm = p.tq_sm;
+      t.part = p.tq_part; t.p_s0 = p.tq_ps0; t.p_s1 = p.tq_ps1; t.p_ts = p.tq_ts; t.nparts = tq_parts - 1; t.M = M; t.nz1 = nr.nz1;
+      prof_begin((std::string(tag) + ".tail_add").c_str(), 0);
+      hipLaunchKernelGGL(k_tail_add, dim3((M + 255) / 256, nz), dim3(256), 0, stream, t);
+      prof_end();
+      if (hipGetLastError() != hipSuccess) return fail("tail_add launch");
+    }
+    return 0;
+  }
   switch (epi) {
-    case E_BIAS_RELU: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, CFG_AUTO, p, nz, tag, a_kpad);
+    case E_BIAS_RELU: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS_RELU>(this, cfg, p, nz, tag, a_kpad);
     case E_BIAS: return run_gemm<PA_PLAIN, PB_PLAIN, E_BIAS>(this, CFG_AUTO, p, nz, tag, a_kpad);
     case E_MASK: return run_gemm<PA_PLAIN, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag, a_kpad);
     default: return run_gemm<PA_PLAIN, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag, a_kpad);
@@ -447,8 +476,11 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     if (err != hipErrorNotSupported) return fail(std::string("fused forward launch ") + tag + ": " + hipGetErrorString(err));
     if (prof_on) prof.pop_back();
   }
+  bool tail_done = false;
   for (int i = 0; i < Ln; ++i)
-    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str())) return -1;
+    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str(), 0, -1,
+                   i == Ln - 1 ? &out : nullptr, i == Ln - 1 ? &tail_done : nullptr)) return -1;
+  if (tail_done) return 0;                 // single-output tail folded into the last hidden layer's epilogue
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
 }
 
@@ -550,6 +582,9 @@ int Engine::build_common() {
   alloc("b_obs2", 2 * B, OP);
   alloc("b_act", B, AP); alloc("b_rew", B, 1); alloc("b_term", B, 1);
   alloc("ones", std::max(B, 16), 1);
+  // column-tile partial sums of fused single-output tails (linear_fwd): up to 3 extra parts of the longest row batch
+  tq_scratch_nets = std::max(2, K);
+  alloc("tq_scratch", 3L * (B + 3L * B * N), 1, tq_scratch_nets);
   return 0;
 }
 

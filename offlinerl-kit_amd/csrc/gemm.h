@@ -89,6 +89,10 @@ struct GemmP {
   // dz0 = C never has to reach HBM for the weight gradient of layer 0 -- the epilogue also produces this row tile's
   // contribution  dW0[n][c] = sum_r dz0[r][n] * X[r][c],  db0[n] = sum_r dz0[r][n]  (exact fp32 MFMA) into split-K slab
   // `row tile index`; Adam sums the slabs.  C == null then skips the store of dz0 altogether.
+  // E_BIAS_RELU with tq_out != null (last hidden layer of a net whose tail is a single output, e.g. a critic): the epilogue
+  // also reduces q_part[m] = sum_n relu(..)[m][n] * tq_w[n] over this tile's columns.  Column tile 0 writes
+  // tq_out[m * tq_sm] (+ the tail bias), column tile t >= 1 writes tq_part[(t-1) * tq_ts + m]; the host adds the parts.
+  ZPtr tq_w, tq_b; float* tq_out; float* tq_part; long tq_s0, tq_s1, tq_sm, tq_ps0, tq_ps1, tq_ts;
   ZPtr w0_x; long w0_xsr; int w0_in;
   float* w0_out; float* w0_bias; long w0_s0, w0_s1, w0_bs1, w0_ks, w0_sr;
 };
@@ -553,6 +557,13 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
     }
     f32x4 bv = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (EPI == E_BIAS || EPI == E_BIAS_RELU) bv = *(const f32x4*)&bias[n_ok ? n : 0];
+    const bool tq = (EPI == E_BIAS_RELU) && (p.tq_out != nullptr);       // uniform
+    f32x4 tw = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float tq_bias = 0.f;
+    if (EPI == E_BIAS_RELU && tq) {
+      if (n_ok) tw = *(const f32x4*)&(p.tq_w.at(z0, z1)[n]);
+      if (tn == 0) tq_bias = p.tq_b.at(z0, z1)[0];
+    }
     if (EPI == E_WGRAD && PA == PA_RANK1 && LA == L_BLK4) __syncthreads();   // the tail-gradient reduction above used smem
 #pragma unroll
     for (int a = 0; a < MA; ++a)
@@ -584,6 +595,15 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
           for (int j = 0; j < 4; ++j) v[j] = hv[i][j] > 0.f ? v[j] : 0.f;
         }
         if (n_ok && m < p.M && (!W0_CAP || p.C != nullptr)) *(f32x4*)&Cg[(long)m * p.c_sr + n] = v;
+        if (EPI == E_BIAS_RELU && tq) {                        // row m of the tile is spread over C4 consecutive lanes
+          float pd = (v[0] * tw[0] + v[1] * tw[1]) + (v[2] * tw[2] + v[3] * tw[3]);
+#pragma unroll
+          for (int o = C4 / 2; o > 0; o >>= 1) pd += __shfl_xor(pd, o);
+          if (c4 == 0 && m < p.M) {
+            if (tn == 0) p.tq_out[z0 * p.tq_s0 + z1 * p.tq_s1 + (long)m * p.tq_sm] = pd + tq_bias;
+            else p.tq_part[z0 * p.tq_ps0 + z1 * p.tq_ps1 + (long)(tn - 1) * p.tq_ts + m] = pd;
+          }
+        }
         if (W0_CAP && w0) {                                    // masked values (zero beyond M / N) back into the staged tile
           if (!(n_ok && m < p.M)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
           *(f32x4*)&cs[r * CP + 4 * c4] = v;
@@ -684,8 +704,9 @@ typedef GemmCfg<2, 4, 2, 4, 32> CfgBig;    // 64 x 256, 8 waves (two per SIMD): 
 typedef GemmCfg<2, 2, 2, 2, 32> CfgMid;    // 64 x 64  : wgrad tiles with split-K
 typedef GemmCfg<1, 4, 1, 1, 64> CfgSmall;  // 16 x 64  : batch-sized (256-row) phases, many workgroups
 typedef GemmCfg<4, 1, 1, 1, 32> CfgTall;   // 64 x 16  : narrow outputs (heads, action-gradient columns)
-typedef GemmCfg<2, 2, 4, 4, 32> CfgSq;     // 128 x 128: many-row forward/dgrad (several runs) and square wgrad tiles
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_AUTO = -1 };
+typedef GemmCfg<2, 2, 4, 4, 32> CfgSq;     // 128 x 128, 4 waves: many-row dgrad (several runs) and square wgrad tiles
+typedef GemmCfg<2, 4, 4, 2, 32> CfgSq8;    // 128 x 128, 8 waves (4 per SIMD with two workgroups per CU): many-row forward
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_SQ8 = 5, CFG_AUTO = -1 };
 
 template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
@@ -717,6 +738,17 @@ static inline int pick_cfg(int M, int N, int K, int nz) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Fused tail of a forward launch (GemmP::tq_*): supported on the big-tile configurations, whose epilogue goes through LDS
+// when the pointers / pitches below are 16-byte aligned.  Returns the number of column tiles (partial sums), 0 if not.
+static inline int tq_fused_parts(int cfg, const GemmP& p, const float* tail_w, long tw_s0, long tw_s1) {
+  const int TN = cfg == CFG_SQ8 ? CfgSq8::TN : (cfg == CFG_BIG ? CfgBig::TN : 0);
+  if (!TN) return 0;
+  if ((p.N & 3) || !aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1) return 0;
+  if (!aligned16(p.bias.p) || (p.bias.s0 & 3) || (p.bias.s1 & 3)) return 0;
+  if (!aligned16(tail_w) || (tw_s0 & 3) || (tw_s1 & 3)) return 0;
+  return (p.N + TN - 1) / TN;
+}
 
 // Can the E_MASK dgrad launch (M x N x K, nz problems) also produce the layer-0 weight gradient in its epilogue (GemmP::w0_*)?
 // Returns the number of split-K slabs it would write (= row tiles), 0 if not.  Mirrors the kernel's conditions.
@@ -783,6 +815,7 @@ static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_
     case CFG_MID: return launch_cfg_prec<CfgMid, PA, PB, EPI>(p, la, lb, nz, st, prec);
     case CFG_SMALL: return launch_cfg_prec<CfgSmall, PA, PB, EPI>(p, la, lb, nz, st, prec);
     case CFG_SQ: return launch_cfg_prec<CfgSq, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    case CFG_SQ8: return launch_cfg_prec<CfgSq8, PA, PB, EPI>(p, la, lb, nz, st, prec);
     default: return launch_cfg_prec<CfgTall, PA, PB, EPI>(p, la, lb, nz, st, prec);
   }
 }

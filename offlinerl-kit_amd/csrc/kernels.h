@@ -571,6 +571,19 @@ __global__ void k_adam(AdamP p) {
   }
 }
 
+// q[m] += part[0][m] + part[1][m] + ... (column-tile partial sums of a tail fused into the last hidden layer's epilogue)
+struct TailAddP { float* out; long o_s0, o_s1, o_sm; const float* part; long p_s0, p_s1, p_ts; int nparts, M, nz1; };
+__global__ void k_tail_add(TailAddP p) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= p.M) return;
+  const int z0 = blockIdx.y / p.nz1, z1 = blockIdx.y - z0 * p.nz1;
+  float* o = p.out + z0 * p.o_s0 + z1 * p.o_s1 + (long)m * p.o_sm;
+  const float* q = p.part + z0 * p.p_s0 + z1 * p.p_s1 + m;
+  float a = *o;
+  for (int t = 0; t < p.nparts; ++t) a += q[(long)t * p.p_ts];
+  *o = a;
+}
+
 // Polyak only (targets whose nets were updated earlier in the step)
 __global__ void k_polyak(float* target, long t_s0, long t_s1, const float* src, long s_s0, long s_s1, long P, float tau) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -37,30 +37,27 @@ int main(int argc, char** argv) {
   auto rep = [&](const char* name, float us) { printf("%-44s %8.1f us  %7.1f TF(alg)\n", name, us, gf / us * 1e-3); };
   auto rep2 = [&](const char* name, float us) { printf("%-52s %8.1f us  %7.1f TF(alg)\n", name, us, gf / us * 1e-3); fflush(stdout); };
 #define FWD(CFG, PREC) { p.a_sr = K; p.a_sk = 1; p.b_sr = K; p.b_sk = 1; \
-    rep2("fwd   " #CFG " " #PREC, time_it([&] { launch_inst<CFG, L_VECK, L_VECK, PA_PLAIN, PB_PLAIN, E_BIAS_RELU, PREC>(p, nz, 0); }, 20)); }
+    rep2("fwd   " #CFG " " #PREC, time_it([&] { (void)launch_inst<CFG, L_VECK, L_VECK, PA_PLAIN, PB_PLAIN, E_BIAS_RELU, PREC>(p, nz, 0); }, 20)); }
 #define DGR(CFG, PREC) { p.a_sr = K; p.a_sk = 1; p.b_sr = 1; p.b_sk = N; p.b_rlim = N; p.a_trans = 0; \
-    rep2("dgrad " #CFG " " #PREC, time_it([&] { launch_inst<CFG, L_VECK, L_BLK4, PA_RANK1, PB_PLAIN, E_MASK, PREC>(p, nz, 0); }, 20)); }
+    rep2("dgrad " #CFG " " #PREC, time_it([&] { (void)launch_inst<CFG, L_VECK, L_BLK4, PA_RANK1, PB_PLAIN, E_MASK, PREC>(p, nz, 0); }, 20)); }
   typedef GemmCfg<2, 2, 4, 4, 32> C_2244;
-  typedef GemmCfg<4, 2, 2, 4, 32> C_4224;
   typedef GemmCfg<2, 4, 4, 2, 32> C_2442;
   typedef GemmCfg<2, 4, 4, 4, 32> C_2444;
-  typedef GemmCfg<2, 2, 2, 4, 32> C_2224;
-  typedef GemmCfg<2, 2, 2, 2, 32> C_2222;
-  typedef GemmCfg<4, 4, 2, 2, 32> C_4422;
-  typedef GemmCfg<2, 4, 2, 4, 32> C_2424;
   typedef GemmCfg<4, 4, 2, 4, 32> C_4424;
-  typedef GemmCfg<1, 4, 4, 4, 32> C_1444;
-  FWD(C_2244, P_BF16X3) FWD(C_2444, P_BF16X3) FWD(C_4424, P_BF16X3) FWD(C_2442, P_BF16X3)
-  DGR(C_2244, P_BF16X3) DGR(C_2444, P_BF16X3) DGR(C_4424, P_BF16X3) DGR(C_2442, P_BF16X3)
-  CK(hipDeviceSynchronize());
+#ifdef ORL_LAB_STAMPS
+  unsigned long long* dst; CK(hipMalloc(&dst, 8 * 16 * 128)); CK(hipMemset(dst, 0, 8 * 16 * 128));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &dst, sizeof(dst)));
+  auto dump = [&](const char* name) {
+    CK(hipDeviceSynchronize());
     std::vector<unsigned long long> st(16 * 128); CK(hipMemcpy(st.data(), dst, 8 * 16 * 128, hipMemcpyDeviceToHost));
-    printf("%s stamps (cycles from kernel-entry stamp; idx: 1 init done, 2 first chunk staged, 3 loads(k+1) issued, 4 mfma done, 5 store done, 6 barrier done, 7.. second iter, 12 loop done, 13 epilogue done)\n", name);
-    for (int b : {0, 1, 8, 60, 100, 127}) { printf("  blk %3d:", b); for (int i = 1; i < 14; ++i) printf(" %6lld", st[b * 16 + i] ? (long long)(st[b * 16 + i] - st[b * 16]) : -1LL); printf("\n"); }
+    printf("%s stamps (cycles after the kernel-entry stamp; 1 init done, 2 first chunk staged, 12 loop done, 13 epilogue done)\n", name);
+    for (int b : {0, 1, 8, 60, 100}) { printf("  blk %3d:", b); for (int i : {1, 2, 12, 13}) printf(" %6lld", st[b * 16 + i] ? (long long)(st[b * 16 + i] - st[b * 16]) : -1LL); printf("\n"); }
   };
   FWD(C_2244, P_BF16X3) dump("fwd");
   DGR(C_2244, P_BF16X3) dump("dgrad");
 #else
-  FWD(C_2244, P_BF16X3) DGR(C_2244, P_BF16X3)
+  FWD(C_2244, P_BF16X3) FWD(C_2444, P_BF16X3) FWD(C_4424, P_BF16X3) FWD(C_2442, P_BF16X3)
+  DGR(C_2244, P_BF16X3) DGR(C_2444, P_BF16X3) DGR(C_4424, P_BF16X3) DGR(C_2442, P_BF16X3)
 #endif
   CK(hipDeviceSynchronize());
   printf("done\n");
