@@ -359,6 +359,7 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
   int TM, TN, TK;
   switch (cfg) {
     case CFG_SQ: TM = CfgSq::TM; TN = CfgSq::TN; TK = CfgSq::kTK; break;
+    case CFG_WG: TM = CfgWg::TM; TN = CfgWg::TN; TK = CfgWg::kTK; break;
     case CFG_BIG: TM = CfgBig::TM; TN = CfgBig::TN; TK = CfgBig::kTK; break;
     case CFG_MID: TM = CfgMid::TM; TN = CfgMid::TN; TK = CfgMid::kTK; break;
     case CFG_SMALL: TM = CfgSmall::TM; TN = CfgSmall::TN; TK = CfgSmall::kTK; break;

@@ -108,6 +108,10 @@ struct GemmCfg {
   static constexpr size_t lds_bytes(int prec) {
     return prec == P_F32 ? sizeof(float) * LDS_FLOATS : (size_t)2 /*buf*/ * 2 /*hi,lo*/ * (TM + TN) * PITCH_H * 2;
   }
+  // LDS the epilogue may use for the staged C tile: the operand buffers, or (when those already limit a CU to one
+  // workgroup) the whole 160 KB
+  static constexpr size_t epi_lds_limit(int prec) { return lds_bytes(prec) > 80 * 1024 ? (size_t)160 * 1024 : lds_bytes(prec); }
+  static constexpr size_t epi_lds_bytes() { return sizeof(float) * (size_t)TM * (TN + 4); }
   static_assert(TK % 16 == 0, "TK multiple of 16");
 };
 
@@ -215,20 +219,35 @@ struct TileLoader {
           o[j] = v;
         }
       } else {  // L_BLK4
-        f32x4 cv;
-        if (PRO == PA_RANK1 && IS_A) cv = *(const f32x4*)&colv[grow[i]];
+        // all global loads of the slot are issued before anything consumes them (a branch between a load and its use
+        // would otherwise serialise the four row fetches)
+        f32x4 vv[4];
+        float rvv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const bool kv = !TAIL || (gk + j) < p.K;
           const float* src = kv ? gk0 + goff[i] + (long)j * sk : g + goff[i] - (long)kin[i] * sk;
-          f32x4 v = *(const f32x4*)src;
-          if (PRO == PA_RANK1 && IS_A) {
-            const float rv = rowv[kv ? gk + j : 0];
-            if (p.tail_w_out && kv) {       // uniform branch: raw v = post-ReLU activation (>= 0)
+          vv[j] = *(const f32x4*)src;
+          if (PRO == PA_RANK1 && IS_A) rvv[j] = rowv[kv ? gk + j : 0];
+        }
+        f32x4 cv;
+        if (PRO == PA_RANK1 && IS_A) cv = *(const f32x4*)&colv[grow[i]];
+        if (PRO == PA_RANK1 && IS_A && p.tail_w_out) {       // uniform branch: raw vv = post-ReLU activation (>= 0)
 #pragma unroll
-              for (int rr = 0; rr < 4; ++rr) tacc[i * 4 + rr] += rv * v[rr];
-              if (((tid + i * NT) % (ROWS / 4)) == 0) bacc += rv;
-            }
+          for (int j = 0; j < 4; ++j) {
+            const bool kv = !TAIL || (gk + j) < p.K;
+            const float rv = kv ? rvv[j] : 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) tacc[i * 4 + rr] += rv * vv[j][rr];
+            if (((tid + i * NT) % (ROWS / 4)) == 0) bacc += rv;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool kv = !TAIL || (gk + j) < p.K;
+          f32x4 v = vv[j];
+          if (PRO == PA_RANK1 && IS_A) {
+            const float rv = rvv[j];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) v[rr] = v[rr] > 0.f ? rv * cv[rr] : 0.f;
           }
@@ -520,7 +539,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   // 64-byte pieces of 16 different rows per instruction.  Stage the TM x TN tile through LDS (the operand buffers are dead)
   // and let every wave move whole row segments: 64 lanes x 16 B = two 512-B runs (TN = 128) per instruction.
   constexpr int CP = TN + 4;                                   // LDS pitch of the staged C tile (floats)
-  constexpr bool LDS_EPI_FITS = (size_t)TM * CP * sizeof(float) <= CFG::lds_bytes(PREC) && (NT % (TN / 4)) == 0;
+  constexpr bool LDS_EPI_FITS = (size_t)TM * CP * sizeof(float) <= CFG::epi_lds_limit(PREC) && (NT % (TN / 4)) == 0;
   constexpr bool W0_CAP = (EPI == E_MASK) && (TN / (NT / 64) == 32) && (TM % 16 == 0);
   const bool w0 = W0_CAP && (p.w0_out != nullptr);             // uniform; the host only asks when the LDS path below is taken
   if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
@@ -706,13 +725,15 @@ typedef GemmCfg<1, 4, 1, 1, 64> CfgSmall;  // 16 x 64  : batch-sized (256-row) p
 typedef GemmCfg<4, 1, 1, 1, 32> CfgTall;   // 64 x 16  : narrow outputs (heads, action-gradient columns)
 typedef GemmCfg<2, 2, 4, 4, 32> CfgSq;     // 128 x 128, 4 waves: many-row dgrad (several runs) and square wgrad tiles
 typedef GemmCfg<2, 4, 4, 2, 32> CfgSq8;    // 128 x 128, 8 waves (4 per SIMD with two workgroups per CU): many-row forward
-enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_SQ8 = 5, CFG_AUTO = -1 };
+typedef GemmCfg<4, 2, 4, 4, 32> CfgWg;     // 256 x 128, 8 waves: weight gradients of 256-wide layers (each dz column block is read once)
+enum { CFG_BIG = 0, CFG_MID = 1, CFG_SMALL = 2, CFG_TALL = 3, CFG_SQ = 4, CFG_SQ8 = 5, CFG_WG = 6, CFG_AUTO = -1 };
 
 template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   const int tiles = ((p.M + CFG::TM - 1) / CFG::TM) * ((p.N + CFG::TN - 1) / CFG::TN);
   dim3 grid((tiles * p.ksplit + 7) & ~7, 1, nz), block(CFG::NT);     // padded to the 8 XCDs (see the kernel's tile mapping)
   size_t lds = CFG::lds_bytes(PREC);
+  if (CFG::epi_lds_bytes() <= CFG::epi_lds_limit(PREC)) lds = std::max(lds, CFG::epi_lds_bytes());   // staged C tile (kernel: LDS_EPI_FITS)
   if (EPI == E_MASK && p.w0_out) lds = std::max(lds, sizeof(float) * ((size_t)CFG::TM * (CFG::TN + 4) + (size_t)CFG::TM * W0_XP));
   auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI, PREC>;
   if (lds > 64 * 1024) {
@@ -733,7 +754,7 @@ static inline int pick_cfg(int M, int N, int K, int nz) {
   if (M >= 2048 && N >= 128) return ((long)M * nz >= 40000) ? CFG_SQ : CFG_BIG;   // few rows: 8-wave 64x256 fills the CUs
   if (M <= 32) return CFG_SMALL;
   // long reductions (wgrad over thousands of rows): square tiles + split-K; batch-sized products: many small workgroups
-  if (K >= 1024) return (M >= 128 && N >= 128) ? CFG_SQ : CFG_MID;
+  if (K >= 1024) return (M >= 256 && N >= 128) ? CFG_WG : ((M >= 128 && N >= 128) ? CFG_SQ : CFG_MID);
   return CFG_SMALL;
 }
 
@@ -816,6 +837,7 @@ static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_
     case CFG_SMALL: return launch_cfg_prec<CfgSmall, PA, PB, EPI>(p, la, lb, nz, st, prec);
     case CFG_SQ: return launch_cfg_prec<CfgSq, PA, PB, EPI>(p, la, lb, nz, st, prec);
     case CFG_SQ8: return launch_cfg_prec<CfgSq8, PA, PB, EPI>(p, la, lb, nz, st, prec);
+    case CFG_WG: return launch_cfg_prec<CfgWg, PA, PB, EPI>(p, la, lb, nz, st, prec);
     default: return launch_cfg_prec<CfgTall, PA, PB, EPI>(p, la, lb, nz, st, prec);
   }
 }

@@ -42,8 +42,21 @@ int main(int argc, char** argv) {
     rep2("dgrad " #CFG " " #PREC, time_it([&] { (void)launch_inst<CFG, L_VECK, L_BLK4, PA_RANK1, PB_PLAIN, E_MASK, PREC>(p, nz, 0); }, 20)); }
   typedef GemmCfg<2, 2, 4, 4, 32> C_2244;
   typedef GemmCfg<2, 4, 4, 2, 32> C_2442;
+  typedef GemmCfg<2, 2, 2, 2, 32> C_2222;
+  typedef GemmCfg<2, 4, 8, 4, 32> C_2484;
+  typedef GemmCfg<4, 2, 4, 8, 32> C_4248;
+  typedef GemmCfg<4, 2, 4, 4, 32> C_4244;
   typedef GemmCfg<2, 4, 4, 4, 32> C_2444;
   typedef GemmCfg<4, 4, 2, 4, 32> C_4424;
+  // wgrad-like: dW[out x in] = dz^T h over `rows` rows, rank-1 virtual dz; both operands row-contiguous
+  const int rows = M;
+  float* dG; CK(hipMalloc(&dG, 4L * 32 * (256 * 256 + 1024) * nz)); 
+#define WGR(CFG, PREC, KS, TAILG) { GemmP w = p; w.M = 256; w.N = 256; w.K = rows; w.a_sr = 1; w.a_sk = 256; w.b_sr = 1; w.b_sk = 256; \
+    w.a_rlim = 256; w.b_rlim = 256; w.a_trans = 1; w.ksplit = KS; w.ones_row = 1 << 30; w.A = {dA, 0, nA}; w.B = {dH, 0, nC}; \
+    w.C = dG; w.c_sr = 256; w.c_sn = 1; w.c_s1 = 32L * (65536 + 1024); w.c_ks = 65536 + 1024; w.bias_out = dG + 65536; w.bo_s1 = w.c_s1; w.bo_ks = w.c_ks; \
+    if (TAILG) { w.tail_w_out = dG + 65536 + 256; w.tail_b_out = dG + 65536 + 512; w.tw_s1 = w.c_s1; w.tb_s1 = w.c_s1; } \
+    rep2("wgrad " #CFG " " #PREC " ks=" #KS " tail=" #TAILG, time_it([&] { (void)launch_inst<CFG, L_BLK4, L_BLK4, PA_RANK1, PB_PLAIN, E_WGRAD, PREC>(w, nz, 0); }, 20)); \
+    if (!TAILG) rep2("wgrad(plain A) " #CFG " " #PREC " ks=" #KS, time_it([&] { (void)launch_inst<CFG, L_BLK4, L_BLK4, PA_PLAIN, PB_PLAIN, E_WGRAD, PREC>(w, nz, 0); }, 20)); }
 #ifdef ORL_LAB_STAMPS
   unsigned long long* dst; CK(hipMalloc(&dst, 8 * 16 * 128)); CK(hipMemset(dst, 0, 8 * 16 * 128));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &dst, sizeof(dst)));
@@ -53,11 +66,10 @@ int main(int argc, char** argv) {
     printf("%s stamps (cycles after the kernel-entry stamp; 1 init done, 2 first chunk staged, 12 loop done, 13 epilogue done)\n", name);
     for (int b : {0, 1, 8, 60, 100}) { printf("  blk %3d:", b); for (int i : {1, 2, 12, 13}) printf(" %6lld", st[b * 16 + i] ? (long long)(st[b * 16 + i] - st[b * 16]) : -1LL); printf("\n"); }
   };
-  FWD(C_2244, P_BF16X3) dump("fwd");
-  DGR(C_2244, P_BF16X3) dump("dgrad");
+  WGR(C_2244, P_BF16X3, 4, 1) dump("wgrad");
 #else
-  FWD(C_2244, P_BF16X3) FWD(C_2444, P_BF16X3) FWD(C_4424, P_BF16X3) FWD(C_2442, P_BF16X3)
-  DGR(C_2244, P_BF16X3) DGR(C_2444, P_BF16X3) DGR(C_4424, P_BF16X3) DGR(C_2442, P_BF16X3)
+  FWD(C_2442, P_BF16X3) FWD(C_2444, P_BF16X3) FWD(C_4244, P_BF16X3)
+  DGR(C_2244, P_BF16X3) DGR(C_2444, P_BF16X3) DGR(C_4244, P_BF16X3)
 #endif
   CK(hipDeviceSynchronize());
   printf("done\n");
