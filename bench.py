@@ -134,6 +134,22 @@ def cpu_baseline(seconds=14.0):
                        f"({best[1]} of {cands} tried; host has {ncpu} cpus)")
 
 
+def pmc_traffic(tag, runs, precision):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction; profiles/pmc_traffic.json).
+    PMC counters cannot be collected from inside the timed process, so the figure is only reported when the committed
+    measurement was taken on the same kernel tag, run count and precision; otherwise null."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(tag)
+        if e and e["runs_per_gpu"] == runs and e["precision"] == precision:
+            return e["bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,7 +268,8 @@ def main():
                 peak = PEAK_TFLOPS[args.precision]
                 gbps = top["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
                 roof = dict(bound="mfma", kernel=top["name"], achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-                            traffic=None, avg_launch_ms=avg_ms, flops_per_launch=top["flops_per_launch"],
+                            traffic=pmc_traffic(top["name"], R, args.precision), avg_launch_ms=avg_ms,
+                            flops_per_launch=top["flops_per_launch"],
                             # the same launch against the HBM roof (algorithmic bytes: operands read once, result written once)
                             hbm=dict(bytes_per_launch=top["bytes_per_launch"], achieved=gbps, peak=8000.0, unit="GB/s", frac=gbps / 8000.0),
                             step_frac_of_mlp_gemm_roofline=(value / world) * flops_step / (peak * 1e12),
