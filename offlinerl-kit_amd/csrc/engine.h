@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -59,10 +60,14 @@ struct Mat {
   float* p = nullptr;
   long rs = 0, cs = 0;  // run stride, member stride (elements)
   int pitch = 0;
-  Mat rows(long r0) const { Mat m = *this; m.p = p + r0 * pitch; return m; }
-  Mat cols(int c0) const { Mat m = *this; m.p = p + c0; return m; }
-  Mat net(int c) const { Mat m = *this; m.p = p + c * cs; return m; }
-  Mat shared() const { Mat m = *this; m.cs = 0; return m; }
+  // packed ReLU-mask bits of a hidden activation (gemm.h, GemmP::mb_out): 16 bytes per (row, 128 columns); strides in words
+  unsigned int* bits = nullptr;
+  long brs = 0, bcs = 0;
+  int bg = 0;
+  Mat rows(long r0) const { Mat m = *this; m.p = p + r0 * pitch; if (bits) m.bits = bits + r0 * bg * 4; return m; }
+  Mat cols(int c0) const { Mat m = *this; m.p = p + c0; m.bits = nullptr; return m; }
+  Mat net(int c) const { Mat m = *this; m.p = p + c * cs; if (bits) m.bits = bits + c * bcs; return m; }
+  Mat shared() const { Mat m = *this; m.cs = 0; m.bcs = 0; return m; }
 };
 struct NetRef {
   float* base = nullptr;  // params of run 0, member 0
@@ -117,6 +122,7 @@ struct Engine {
   std::vector<void*> allocs;
   std::map<std::string, Mat> ws;
   std::map<std::string, long> ws_len;
+  std::set<const void*> bits_live;   // mask-bit buffers whose producer launch emitted them this step (decided on the host)
   struct Tap { Mat m; long rows; int cols; };
   std::map<std::string, Tap> taps;
   struct NoiseSlot { std::string name; int kind; int rows; };

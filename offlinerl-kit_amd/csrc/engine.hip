@@ -183,6 +183,11 @@ Mat Engine::alloc(const std::string& name, long rows, int pitch, int nets) {
   m.rs = per_run;
   m.cs = per_net;
   m.pitch = pitch;
+  if (pitch >= 128 && (pitch & 127) == 0) {          // hidden-activation shaped: room for the packed ReLU masks
+    m.bg = pitch / 128;
+    m.bcs = rows * m.bg * 4; m.brs = m.bcs * nets;
+    m.bits = (unsigned int*)raw_alloc(sizeof(unsigned int) * m.brs * R);
+  }
   ws[name] = m;
   ws_len[name] = per_run;
   return m;
@@ -277,6 +282,12 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   const int nz = R * nr.nz1;
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
+  if (Y.bits) {
+    if (epi == E_BIAS_RELU && !force_scalar && out == Y.pitch && mb_supported(cfg, p)) {
+      p.mb_out = Y.bits; p.mb_s0 = Y.brs; p.mb_s1 = Y.bcs; p.mb_g = Y.bg;
+      bits_live.insert(Y.bits);
+    } else bits_live.erase(Y.bits);
+  }
   if (tail_fused) *tail_fused = false;
   int tq_parts = 0;
   if (tail_out && tail_fused && epi == E_BIAS_RELU && layer == l.L - 1 && l.out_dim == 1 && !force_scalar && ws.count("tq_scratch")) {
@@ -333,6 +344,9 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
   const int nz = R * nr.nz1;
   if (w0_slabs) *w0_slabs = 0;
+  if (maskH && maskH->bits && bits_live.count(maskH->bits) && ncols == maskH->pitch && aligned16(maskH->p) && (maskH->pitch & 3) == 0) {
+    p.aux_bits = maskH->bits; p.xb_s0 = maskH->brs; p.xb_s1 = maskH->bcs; p.xb_g = maskH->bg;
+  }
   if (w0_X && w0_slabs && maskH && layer == 1 && col0 == 0 && !l.ens && !force_scalar) {
     // fuse the layer-0 weight / bias gradient into this launch's epilogue (one slab per row tile)
     const int slabs = w0_fused_slabs(p, nz, l.layer_in(0), w0_X->pitch, w0_X->p, w0_X->rs, w0_X->cs, max_slab);
@@ -346,6 +360,22 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     }
   }
   if (dy.rank1) {
+    if (maskH && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch) {
+      // the virtual dz of the top hidden layer from its packed ReLU mask: the activation matrix is not read at all
+      GemmP q = p;
+      q.a_bits = dy.m.bits; q.ab_s0 = dy.m.brs; q.ab_s1 = dy.m.bcs; q.ab_g = dy.m.bg;
+      const int tcfg = pick_cfg(q.M, q.N, q.K, nz);
+      if (rank1_bits_supported(tcfg, q, force_scalar)) {
+        const double flops = 2.0 * q.M * (double)q.N * q.K * nz + (q.w0_out ? 2.0 * q.M * (double)q.N * (q.w0_in + 1) * nz : 0.0);
+        const double bytes = nz * (4.0 * q.N * q.K + q.M * (double)q.K / 8 + (q.C ? 4.0 * q.M * q.N : 0.0) +
+                                   (q.aux_bits ? q.M * (double)q.N / 8 : 4.0 * q.M * q.N) + (q.w0_out ? 4.0 * q.M * q.w0_xsr : 0.0));
+        prof_begin(tag, flops, bytes);
+        hipError_t err = launch_gemm_rank1_bits<E_MASK>(tcfg, q, nz, stream, this->cfg.precision);
+        prof_end();
+        if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
+        return 0;
+      }
+    }
     if (maskH) return run_gemm<PA_RANK1, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
     return run_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
   }
@@ -624,7 +654,7 @@ int Engine::init(const orl_config& c) {
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
-  use_fused = getenv("ORL_FUSED") != nullptr;   // opt-in: measured slower than the layer-wise kernels
+  { const char* f = getenv("ORL_FUSED"); use_fused = f && atoi(f) != 0; }   // opt-in: measured slower than the layer-wise kernels
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {

@@ -44,7 +44,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per operand, 3/16 of the fp32 MFMA cycles)
 enum { P_F32 = 0, P_BF16X3 = 1 };
 
-enum { PA_PLAIN = 0, PA_RANK1 = 1 };                                   // prologue on A elements
+enum { PA_PLAIN = 0, PA_RANK1 = 1, PA_RANK1B = 2 };                    // prologue on A elements (RANK1B: ReLU mask from packed bits)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 enum { PB_PLAIN = 0, PB_ONES = 1 };                                    // prologue on B elements
 enum { E_PLAIN = 0, E_BIAS = 1, E_BIAS_RELU = 2, E_MASK = 3, E_WGRAD = 4 };
 enum { L_SCALAR = 0, L_VECK = 1, L_BLK4 = 2, L_VECKU = 3 };            // operand loaders
@@ -93,6 +94,14 @@ struct GemmP {
   // also reduces q_part[m] = sum_n relu(..)[m][n] * tq_w[n] over this tile's columns.  Column tile 0 writes
   // tq_out[m * tq_sm] (+ the tail bias), column tile t >= 1 writes tq_part[(t-1) * tq_ts + m]; the host adds the parts.
   ZPtr tq_w, tq_b; float* tq_out; float* tq_part; long tq_s0, tq_s1, tq_sm, tq_ps0, tq_ps1, tq_ts;
+  // Packed ReLU masks.  One 16-byte group per (row, 128 columns): word j (0..3), bit c (0..31) <-> column 128*g + 4*c + j
+  // of the group is set when the activation is > 0.  `*_g` = groups per row; z strides in 32-bit words.
+  //   mb_out   (E_BIAS_RELU epilogue through LDS, TN multiple of 128): also emit the mask of the produced activation
+  //   aux_bits (E_MASK): read the mask from bits instead of the activation matrix `aux`
+  //   a_bits   (PA_RANK1B, L_VECK, a_trans = 0): a(m, k) = bit(m, k) ? rowv[m] * colv[k] : 0 without reading A
+  unsigned int* mb_out; long mb_s0, mb_s1; int mb_g;
+  const unsigned int* aux_bits; long xb_s0, xb_s1; int xb_g;
+  const unsigned int* a_bits; long ab_s0, ab_s1; int ab_g;
   ZPtr w0_x; long w0_xsr; int w0_in;
   float* w0_out; float* w0_bias; long w0_s0, w0_s1, w0_bs1, w0_ks, w0_sr;
 };
@@ -196,6 +205,16 @@ struct TileLoader {
         o[0] = kv ? v : 0.f;
       } else if (LMODE == L_VECK) {
         const bool kv = !TAIL || gk < p.K;               // K % 4 == 0 or zero-padded rows (host guarantees)
+        if (PRO == PA_RANK1B && IS_A) {                  // `g` = packed mask words of this z; A itself is never read
+          const int kk = kv ? gk : 0;
+          const u32x4 w = *(const u32x4*)((const unsigned int*)g + ((long)grow[i] * p.ab_g + (kk >> 7)) * 4);
+          const int c = (kk & 127) >> 2;
+          const float rv = rowv[grow[i]];
+          const f32x4 cv = *(const f32x4*)&colv[kk];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (kv && ((w[j] >> c) & 1u)) ? rv * cv[j] : 0.f;
+          continue;
+        }
         const float* src = kv ? gk0 + goff[i] : g + goff[i] - kin[i];
         f32x4 v = *(const f32x4*)src;
         if (PRO == PA_RANK1 && IS_A) {
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * TM, n0 = tn * TN;
 
-  const float* __restrict__ Ag = p.A.at(z0, z1);
+  const float* __restrict__ Ag = (PA == PA_RANK1B) ? (const float*)(p.a_bits + z0 * p.ab_s0 + z1 * p.ab_s1) : p.A.at(z0, z1);
   const float* __restrict__ Bg = p.B.at(z0, z1);
   const float* __restrict__ rowv = p.rowv.at(z0, z1);
   const float* __restrict__ colv = p.colv.at(z0, z1);
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const float* __restrict__ aux = p.aux.at(z0, z1);
   float* bo = (EPI == E_WGRAD && p.bias_out) ? p.bias_out + z0 * p.bo_s0 + z1 * p.bo_s1 + (long)ks * p.bo_ks : nullptr;
   const bool vec_ok = (p.c_sn == 1) && ((p.c_sr & 3) == 0) && ((((uintptr_t)Cg) & 15) == 0) &&
-                      (EPI != E_MASK || (((p.aux_sr & 3) == 0) && ((((uintptr_t)aux) & 15) == 0))) &&
+                      (EPI != E_MASK || p.aux_bits != nullptr || (((p.aux_sr & 3) == 0) && ((((uintptr_t)aux) & 15) == 0))) &&
                       ((EPI != E_BIAS && EPI != E_BIAS_RELU) || ((((uintptr_t)bias) & 15) == 0));
   if (EPI == E_WGRAD && PA == PA_RANK1 && LA == L_BLK4) {
     if (p.tail_w_out && tn == 0) {
@@ -545,17 +564,21 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
     float* cs = smem;
     constexpr int C4 = TN / 4, RPP = NT / C4, NPASS = (TM + RPP - 1) / RPP;   // float4 columns per row, rows per pass
+    constexpr bool MB_CAP = (TN % 128) == 0 && (C4 == 32 || C4 == 64);          // a row's 128-column groups are 32-lane halves of a wave
     const int c4 = tid % C4, r0 = tid / C4;
     const int n = n0 + 4 * c4;
     const bool n_ok = n < p.N;
     // the mask tile is fetched first (clamped addresses, no branches) so its latency hides behind the LDS staging
     f32x4 hv[EPI == E_MASK ? NPASS : 1];
+    const bool xbits = (EPI == E_MASK) && (p.aux_bits != nullptr);           // uniform: the mask comes as packed bits
     if (EPI == E_MASK) {
+      const unsigned int* xb = p.aux_bits + z0 * p.xb_s0 + z1 * p.xb_s1;
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         int m = m0 + r0 + i * RPP;
         m = m < p.M ? m : p.M - 1;
-        hv[i] = *(const f32x4*)&aux[(long)m * p.aux_sr + (n_ok ? n : 0)];
+        if (xbits) hv[i] = *(const f32x4*)(xb + ((long)m * p.xb_g + ((n_ok ? n : 0) >> 7)) * 4);
+        else hv[i] = *(const f32x4*)&aux[(long)m * p.aux_sr + (n_ok ? n : 0)];
       }
     }
     // fused layer-0 weight gradient: this thread's pieces of the X tile [TM][W0_XP], fetched now for the same reason
@@ -610,8 +633,21 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
           for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
         }
         if (EPI == E_MASK) {
+          if (xbits) {
+            const int c = (n & 127) >> 2;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = hv[i][j] > 0.f ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = ((__float_as_uint(hv[i][j]) >> c) & 1u) ? v[j] : 0.f;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = hv[i][j] > 0.f ? v[j] : 0.f;
+          }
+        }
+        if (EPI == E_BIAS_RELU && MB_CAP && p.mb_out) {        // uniform: emit the packed mask of this tile's rows
+          u32x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (unsigned int)(__ballot(n_ok && v[j] > 0.f) >> (lane & 32));
+          if ((c4 & 31) == 0 && n_ok && m < p.M)
+            *(u32x4*)(p.mb_out + z0 * p.mb_s0 + z1 * p.mb_s1 + ((long)m * p.mb_g + (n >> 7)) * 4) = w;
         }
         if (n_ok && m < p.M && (!W0_CAP || p.C != nullptr)) *(f32x4*)&Cg[(long)m * p.c_sr + n] = v;
         if (EPI == E_BIAS_RELU && tq) {                        // row m of the tile is spread over C4 consecutive lanes
@@ -771,6 +807,14 @@ static inline int tq_fused_parts(int cfg, const GemmP& p, const float* tail_w, l
   return (p.N + TN - 1) / TN;
 }
 
+// Will a forward launch on `cfg` emit packed mask bits (GemmP::mb_out)?  Same conditions as the fused tail.
+static inline bool mb_supported(int cfg, const GemmP& p) {
+  const int TN = cfg == CFG_SQ8 ? CfgSq8::TN : (cfg == CFG_BIG ? CfgBig::TN : 0);
+  if (!TN || (p.N & 127)) return false;
+  if (!aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1) return false;
+  return aligned16(p.bias.p) && !(p.bias.s0 & 3) && !(p.bias.s1 & 3);
+}
+
 // Can the E_MASK dgrad launch (M x N x K, nz problems) also produce the layer-0 weight gradient in its epilogue (GemmP::w0_*)?
 // Returns the number of split-K slabs it would write (= row tiles), 0 if not.  Mirrors the kernel's conditions.
 static inline int w0_fused_slabs(const GemmP& p, int nz, int in0, long x_pitch, const void* x_ptr, long x_s0, long x_s1, int max_slab) {
@@ -778,7 +822,8 @@ static inline int w0_fused_slabs(const GemmP& p, int nz, int in0, long x_pitch, 
   const int TM = cfg == CFG_SQ ? CfgSq::TM : (cfg == CFG_BIG ? CfgBig::TM : 0);
   if (!TM) return 0;                                                       // tiles whose waves own 32 columns each
   if (in0 + 1 > W0_XP || in0 >= x_pitch || x_pitch > W0_XP || (x_pitch & 3) || !aligned16(x_ptr) || (x_s0 & 3) || (x_s1 & 3)) return 0;
-  if ((p.N & 3) || (p.aux_sr & 3) || !aligned16(p.aux.p) || (p.aux.s0 & 3) || (p.aux.s1 & 3)) return 0;   // LDS epilogue path
+  if (p.N & 3) return 0;
+  if (!p.aux_bits && ((p.aux_sr & 3) || !aligned16(p.aux.p) || (p.aux.s0 & 3) || (p.aux.s1 & 3))) return 0;   // LDS epilogue path
   if (p.C && (!aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1)) return 0;
   const int tiles_m = (p.M + TM - 1) / TM;
   return tiles_m <= max_slab ? tiles_m : 0;
@@ -840,6 +885,28 @@ static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_
     case CFG_WG: return launch_cfg_prec<CfgWg, PA, PB, EPI>(p, la, lb, nz, st, prec);
     default: return launch_cfg_prec<CfgTall, PA, PB, EPI>(p, la, lb, nz, st, prec);
   }
+}
+
+// dgrad whose A operand is the rank-1 virtual gradient rebuilt from packed mask bits: only the shapes the engine uses it for
+// (k-contiguous A side, big tiles); anything else is refused and the caller keeps the float-mask path.
+static inline bool rank1_bits_supported(int cfg, const GemmP& p, bool force_scalar) {
+  if (force_scalar || (cfg != CFG_SQ && cfg != CFG_BIG) || p.a_trans != 0 || (p.K & 127)) return false;
+  if (!aligned16(p.colv.p) || (p.colv.s0 & 3) || (p.colv.s1 & 3) || !aligned16(p.a_bits) || (p.ab_s0 & 3) || (p.ab_s1 & 3)) return false;
+  const int lb = pick_loader(p.B, p.b_sr, p.b_sk, p.K, false, p.b_rlim);
+  return lb == L_BLK4 || lb == L_VECK;
+}
+template <int EPI>
+static inline hipError_t launch_gemm_rank1_bits(int cfg, const GemmP& p, int nz, hipStream_t st, int prec) {
+  if (!rank1_bits_supported(cfg, p, false)) return hipErrorInvalidValue;
+  const int lb = pick_loader(p.B, p.b_sr, p.b_sk, p.K, false, p.b_rlim);
+#define ORL_RB(CFG, LB, PREC) launch_inst<CFG, L_VECK, LB, PA_RANK1B, PB_PLAIN, EPI, PREC>(p, nz, st)
+  if (cfg == CFG_SQ) {
+    if (prec == P_BF16X3) return lb == L_BLK4 ? ORL_RB(CfgSq, L_BLK4, P_BF16X3) : ORL_RB(CfgSq, L_VECK, P_BF16X3);
+    return lb == L_BLK4 ? ORL_RB(CfgSq, L_BLK4, P_F32) : ORL_RB(CfgSq, L_VECK, P_F32);
+  }
+  if (prec == P_BF16X3) return lb == L_BLK4 ? ORL_RB(CfgBig, L_BLK4, P_BF16X3) : ORL_RB(CfgBig, L_VECK, P_BF16X3);
+  return lb == L_BLK4 ? ORL_RB(CfgBig, L_BLK4, P_F32) : ORL_RB(CfgBig, L_VECK, P_F32);
+#undef ORL_RB
 }
 
 // ---- tuning tap (orl_debug_gemm_time): the three hot kernel kinds on the main + two extra tile shapes ----
