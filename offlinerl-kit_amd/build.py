@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liborlengine.so")
 SOURCES = ["engine.hip"]
-HEADERS = ["engine.h", "gemm.h", "kernels.h", os.path.join("..", "..", "include", "orl_engine.h")]
+HEADERS = ["engine.h", "gemm.h", "kernels.h", "ws_gemm.h", "mlp_fused.h", "algo_cql.inc", "algo_iql.inc", "algo_td3bc.inc", "algo_edac.inc",
+           os.path.join("..", "..", "include", "orl_engine.h")]
 
 
 def needs_build():

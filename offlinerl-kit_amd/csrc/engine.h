@@ -11,6 +11,7 @@
 #include "gemm.h"
 #include "kernels.h"
 #include "mlp_fused.h"
+#include "ws_gemm.h"
 
 namespace orl {
 
@@ -60,11 +61,11 @@ struct Mat {
   float* p = nullptr;
   long rs = 0, cs = 0;  // run stride, member stride (elements)
   int pitch = 0;
-  // packed ReLU-mask bits of a hidden activation (gemm.h, GemmP::mb_out): 16 bytes per (row, 128 columns); strides in words
+  // packed ReLU-mask bits of a hidden activation (gemm.h, GemmP::mb_out): one 32-bit word per (row, 32 columns); strides in words
   unsigned int* bits = nullptr;
   long brs = 0, bcs = 0;
   int bg = 0;
-  Mat rows(long r0) const { Mat m = *this; m.p = p + r0 * pitch; if (bits) m.bits = bits + r0 * bg * 4; return m; }
+  Mat rows(long r0) const { Mat m = *this; m.p = p + r0 * pitch; if (bits) m.bits = bits + r0 * bg; return m; }
   Mat cols(int c0) const { Mat m = *this; m.p = p + c0; m.bits = nullptr; return m; }
   Mat net(int c) const { Mat m = *this; m.p = p + c * cs; if (bits) m.bits = bits + c * bcs; return m; }
   Mat shared() const { Mat m = *this; m.cs = 0; m.bcs = 0; return m; }

@@ -184,8 +184,8 @@ Mat Engine::alloc(const std::string& name, long rows, int pitch, int nets) {
   m.cs = per_net;
   m.pitch = pitch;
   if (pitch >= 128 && (pitch & 127) == 0) {          // hidden-activation shaped: room for the packed ReLU masks
-    m.bg = pitch / 128;
-    m.bcs = rows * m.bg * 4; m.brs = m.bcs * nets;
+    m.bg = pitch / 32;                                 // one 32-bit word per 32 columns
+    m.bcs = rows * m.bg; m.brs = m.bcs * nets;
     m.bits = (unsigned int*)raw_alloc(sizeof(unsigned int) * m.brs * R);
   }
   ws[name] = m;
@@ -282,6 +282,33 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   const int nz = R * nr.nz1;
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
+  // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
+  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && !force_scalar && !l.ens && !use_fused && in_row0 == 0 && in_rows == in &&
+      Y.bits && Y.pitch == out && (long)M * nz >= 40000) {
+    WsFwdP w;
+    memset(&w, 0, sizeof(w));
+    w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch;
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    w.bias = nr.base + l.b_off[layer]; w.b_s0 = nr.rs; w.b_s1 = l.b_ms[layer];
+    w.Y = Y.p; w.y_s0 = Y.rs; w.y_s1 = Y.cs; w.y_pitch = Y.pitch;
+    w.mb = Y.bits; w.mb_s0 = Y.brs; w.mb_s1 = Y.bcs; w.mb_g = Y.bg;
+    w.M = M; w.nz1 = nr.nz1;
+    const bool want_tail = tail_out && tail_fused && layer == l.L - 1 && l.out_dim == 1;
+    if (want_tail) {
+      w.tw = nr.base + l.w_off[l.L]; w.tw_s0 = nr.rs; w.tw_s1 = l.w_ms[l.L];
+      w.tb = nr.base + l.b_off[l.L]; w.tb_s0 = nr.rs; w.tb_s1 = l.b_ms[l.L];
+      w.tq = tail_out->p; w.tq_s0 = tail_out->rs; w.tq_s1 = tail_out->cs; w.tq_sm = tail_out->pitch;
+    }
+    if (ws_fwd_supported(w, in, out)) {
+      prof_begin(tag, 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz, 4.0 * nz * ((double)M * in + (double)out * in + (double)M * out));
+      hipError_t err = launch_ws_fwd(w, nz, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
+      bits_live.insert(Y.bits);
+      if (tail_fused) *tail_fused = want_tail;
+      return 0;
+    }
+  }
   if (Y.bits) {
     if (epi == E_BIAS_RELU && !force_scalar && out == Y.pitch && mb_supported(cfg, p)) {
       p.mb_out = Y.bits; p.mb_s0 = Y.brs; p.mb_s1 = Y.bcs; p.mb_g = Y.bg;

@@ -94,9 +94,9 @@ struct GemmP {
   // also reduces q_part[m] = sum_n relu(..)[m][n] * tq_w[n] over this tile's columns.  Column tile 0 writes
   // tq_out[m * tq_sm] (+ the tail bias), column tile t >= 1 writes tq_part[(t-1) * tq_ts + m]; the host adds the parts.
   ZPtr tq_w, tq_b; float* tq_out; float* tq_part; long tq_s0, tq_s1, tq_sm, tq_ps0, tq_ps1, tq_ts;
-  // Packed ReLU masks.  One 16-byte group per (row, 128 columns): word j (0..3), bit c (0..31) <-> column 128*g + 4*c + j
-  // of the group is set when the activation is > 0.  `*_g` = groups per row; z strides in 32-bit words.
-  //   mb_out   (E_BIAS_RELU epilogue through LDS, TN multiple of 128): also emit the mask of the produced activation
+  // Packed ReLU masks: one 32-bit word per (row, 32 columns); bit b of word w of a row <-> column 32 w + b is set when the
+  // activation is > 0.  `*_g` = words per row; z strides in 32-bit words.
+  //   mb_out   (E_BIAS_RELU epilogue through LDS): also emit the mask of the produced activation
   //   aux_bits (E_MASK): read the mask from bits instead of the activation matrix `aux`
   //   a_bits   (PA_RANK1B, L_VECK, a_trans = 0): a(m, k) = bit(m, k) ? rowv[m] * colv[k] : 0 without reading A
   unsigned int* mb_out; long mb_s0, mb_s1; int mb_g;
@@ -207,12 +207,11 @@ struct TileLoader {
         const bool kv = !TAIL || gk < p.K;               // K % 4 == 0 or zero-padded rows (host guarantees)
         if (PRO == PA_RANK1B && IS_A) {                  // `g` = packed mask words of this z; A itself is never read
           const int kk = kv ? gk : 0;
-          const u32x4 w = *(const u32x4*)((const unsigned int*)g + ((long)grow[i] * p.ab_g + (kk >> 7)) * 4);
-          const int c = (kk & 127) >> 2;
+          const unsigned int w = ((const unsigned int*)g)[(long)grow[i] * p.ab_g + (kk >> 5)] >> (kk & 31);
           const float rv = rowv[grow[i]];
           const f32x4 cv = *(const f32x4*)&colv[kk];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (kv && ((w[j] >> c) & 1u)) ? rv * cv[j] : 0.f;
+          for (int j = 0; j < 4; ++j) o[j] = (kv && ((w >> j) & 1u)) ? rv * cv[j] : 0.f;
           continue;
         }
         const float* src = kv ? gk0 + goff[i] : g + goff[i] - kin[i];
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
     float* cs = smem;
     constexpr int C4 = TN / 4, RPP = NT / C4, NPASS = (TM + RPP - 1) / RPP;   // float4 columns per row, rows per pass
-    constexpr bool MB_CAP = (TN % 128) == 0 && (C4 == 32 || C4 == 64);          // a row's 128-column groups are 32-lane halves of a wave
+    constexpr bool MB_CAP = (C4 % 8) == 0;                                     // eight lanes of a row own one 32-column mask word
     const int c4 = tid % C4, r0 = tid / C4;
     const int n = n0 + 4 * c4;
     const bool n_ok = n < p.N;
@@ -577,7 +576,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
       for (int i = 0; i < NPASS; ++i) {
         int m = m0 + r0 + i * RPP;
         m = m < p.M ? m : p.M - 1;
-        if (xbits) hv[i] = *(const f32x4*)(xb + ((long)m * p.xb_g + ((n_ok ? n : 0) >> 7)) * 4);
+        if (xbits) hv[i][0] = __uint_as_float(xb[(long)m * p.xb_g + ((n_ok ? n : 0) >> 5)]);
         else hv[i] = *(const f32x4*)&aux[(long)m * p.aux_sr + (n_ok ? n : 0)];
       }
     }
@@ -634,20 +633,20 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
         }
         if (EPI == E_MASK) {
           if (xbits) {
-            const int c = (n & 127) >> 2;
+            const unsigned int w = __float_as_uint(hv[i][0]) >> (n & 31);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ((__float_as_uint(hv[i][j]) >> c) & 1u) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = ((w >> j) & 1u) ? v[j] : 0.f;
           } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = hv[i][j] > 0.f ? v[j] : 0.f;
           }
         }
         if (EPI == E_BIAS_RELU && MB_CAP && p.mb_out) {        // uniform: emit the packed mask of this tile's rows
-          u32x4 w;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) w[j] = (unsigned int)(__ballot(n_ok && v[j] > 0.f) >> (lane & 32));
-          if ((c4 & 31) == 0 && n_ok && m < p.M)
-            *(u32x4*)(p.mb_out + z0 * p.mb_s0 + z1 * p.mb_s1 + ((long)m * p.mb_g + (n >> 7)) * 4) = w;
+          // 4 bits per lane, 8 consecutive lanes of a row make one 32-bit word (OR-reduction over lane bits 0..2)
+          unsigned int w = 0;
+          if (n_ok) w = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (4 * (c4 & 7));
+          w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+          if ((c4 & 7) == 0 && n_ok && m < p.M) p.mb_out[z0 * p.mb_s0 + z1 * p.mb_s1 + (long)m * p.mb_g + (n >> 5)] = w;
         }
         if (n_ok && m < p.M && (!W0_CAP || p.C != nullptr)) *(f32x4*)&Cg[(long)m * p.c_sr + n] = v;
         if (EPI == E_BIAS_RELU && tq) {                        // row m of the tile is spread over C4 consecutive lanes
@@ -810,7 +809,7 @@ static inline int tq_fused_parts(int cfg, const GemmP& p, const float* tail_w, l
 // Will a forward launch on `cfg` emit packed mask bits (GemmP::mb_out)?  Same conditions as the fused tail.
 static inline bool mb_supported(int cfg, const GemmP& p) {
   const int TN = cfg == CFG_SQ8 ? CfgSq8::TN : (cfg == CFG_BIG ? CfgBig::TN : 0);
-  if (!TN || (p.N & 127)) return false;
+  if (!TN || (p.N & 31)) return false;
   if (!aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1) return false;
   return aligned16(p.bias.p) && !(p.bias.s0 & 3) && !(p.bias.s1 & 3);
 }
@@ -890,8 +889,8 @@ static inline hipError_t launch_gemm(int cfg, const GemmP& p, int nz, hipStream_
 // dgrad whose A operand is the rank-1 virtual gradient rebuilt from packed mask bits: only the shapes the engine uses it for
 // (k-contiguous A side, big tiles); anything else is refused and the caller keeps the float-mask path.
 static inline bool rank1_bits_supported(int cfg, const GemmP& p, bool force_scalar) {
-  if (force_scalar || (cfg != CFG_SQ && cfg != CFG_BIG) || p.a_trans != 0 || (p.K & 127)) return false;
-  if (!aligned16(p.colv.p) || (p.colv.s0 & 3) || (p.colv.s1 & 3) || !aligned16(p.a_bits) || (p.ab_s0 & 3) || (p.ab_s1 & 3)) return false;
+  if (force_scalar || (cfg != CFG_SQ && cfg != CFG_BIG) || p.a_trans != 0 || (p.K & 31)) return false;
+  if (!aligned16(p.colv.p) || (p.colv.s0 & 3) || (p.colv.s1 & 3)) return false;
   const int lb = pick_loader(p.B, p.b_sr, p.b_sk, p.K, false, p.b_rlim);
   return lb == L_BLK4 || lb == L_VECK;
 }

@@ -1,0 +1,257 @@
+// ws_gemm.h — weight-stationary, row-streaming kernels for the 256-wide critic layers of a many-row batch.
+//
+// The generic tile kernel (gemm.h) spends about half of a workgroup's lifetime in its prologue / epilogue when K is
+// only 256 (eight K chunks per tile) and re-reads the weight tile for every row tile.  For the hot shapes of the
+// update engine (hidden layers of width 256 evaluated on thousands of rows: CQL's 7936-row critic batch, reference
+// cql.py:132-190) the whole weight matrix fits in ONE CU's register file once it is split into bf16 hi/lo planes
+// (256 x 256 x 4 B = 256 KB of the 512 KB VGPR file).  So:
+//
+//   * a workgroup = 8 waves; wave w owns output columns [32w, 32w+32) and keeps the B fragments of those columns for
+//     the complete K = 256 in registers (2 column blocks x 8 k-steps x {hi, lo} x 4 VGPRs = 128 VGPRs), loaded and
+//     split ONCE per workgroup;
+//   * the workgroup then streams row groups of 64 rows: the fp32 rows are fetched with full-row coalesced loads,
+//     split into bf16 hi/lo while they are staged into a double-buffered LDS image, and every wave multiplies the
+//     shared A fragments against its resident B fragments (v_mfma_f32_16x16x32_bf16, lo*hi + hi*lo + hi*hi, fp32
+//     accumulation) -- one barrier per 64 rows, no per-tile pipeline fill / drain, no weight traffic in the loop;
+//   * the epilogue works on the wave's own 16 x 32 accumulator blocks (bias, ReLU, packed ReLU-mask bits, the fused
+//     single-output tail q = h . w_tail + b_tail), so it needs no LDS round trip.
+//
+// Per row group and CU: 64 KB of HBM reads against 2 x 192 MFMAs per SIMD (6144 cycles), i.e. the kernel sits at the
+// crossover of the HBM and matrix-pipe rooflines instead of far below both.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm.h"
+
+namespace orl {
+
+struct WsFwdP {
+  const float* X; long x_s0, x_s1; int x_pitch;        // input activations [z][M][K] fp32, K == 256
+  const float* W; long w_s0, w_s1;                      // weights (out, in) row-major [z][256][256]
+  const float* bias; long b_s0, b_s1;
+  float* Y; long y_s0, y_s1; int y_pitch;               // relu(X W^T + b) [z][M][256]
+  unsigned int* mb; long mb_s0, mb_s1; int mb_g;        // packed ReLU mask of Y (gemm.h layout) or null
+  const float* tw; long tw_s0, tw_s1;                   // fused tail: q[m] = Y[m] . tw + tb  (null = off)
+  const float* tb; long tb_s0, tb_s1;
+  float* tq; long tq_s0, tq_s1, tq_sm;
+  int M, nz1, groups;                                   // groups = ceil(M / WS_ROWS)
+};
+
+#ifndef WS_WAVES
+#define WS_WAVES 8      // 16 waves (16 columns each) measured slower: the 128-VGPR budget spills
+#endif
+enum { WS_ROWS = 32, WS_K = 256, WS_N = 256, WS_PITCH = WS_K, WS_NW = WS_WAVES, WS_NT = 64 * WS_NW, WS_CB = WS_N / 16 / WS_NW };   // unpadded rows: 16-byte chunks are XOR-swizzled; WS_CB 16-column blocks per wave
+enum { WS_SUB = WS_ROWS / 16, WS_LD = WS_ROWS * WS_K / 4 / WS_NT };   // 16-row blocks per group; float4 loads per thread per group
+// LDS: A image [2 buffers][hi, lo][WS_ROWS][256] bf16 (swizzled) + tail partial sums [2][WS_NW waves][WS_ROWS] floats
+//      + ReLU-mask nibbles [2][WS_ROWS][64] bytes
+static constexpr size_t ws_fwd_lds_bytes() { return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * 64; }
+
+__device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 ha = (__bf16)a[j]; h[j] = ha; l[j] = (__bf16)(a[j] - (float)ha);
+    const __bf16 hb = (__bf16)b[j]; h[4 + j] = hb; l[4 + j] = (__bf16)(b[j] - (float)hb);
+  }
+}
+
+template <bool TQ>
+__global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
+  float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
+  unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
+  const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
+  float* __restrict__ Yg = p.Y + z0 * p.y_s0 + z1 * p.y_s1;
+  const int ncol0 = 16 * WS_CB * wave;
+
+  // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
+  bf16x8 bh[WS_CB][8], bl[WS_CB][8];
+#pragma unroll
+  for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float* src = Wg + (long)(ncol0 + 16 * cb + li) * WS_K + 32 * ks + 8 * lq;
+      ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
+    }
+  // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r are re-read per row group (L1 hits) rather than
+  // held in 16 VGPRs next to the 128 VGPRs of resident B fragments
+  const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
+  const float tbias = TQ ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
+
+  // ---- staging of one row group: thread t moves float4 #(t + 512 i), i = 0..7, of the [64][256] tile ----
+  // one staging register set: refilled with group g + 2 gs right after group g + gs has been written to LDS
+  f32x4 st0[WS_LD];
+  auto load_group = [&](int g, f32x4 (&st)[WS_LD]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WS_LD; ++i) {
+      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      int m = g * WS_ROWS + r; m = m < p.M ? m : p.M - 1;
+      st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
+    }
+  };
+  auto store_group = [&](int buf, const f32x4 (&st)[WS_LD]) __attribute__((always_inline)) {
+    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+#pragma unroll
+    for (int i = 0; i < WS_LD; ++i) {
+      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      bf16x4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)st[i][j]; h[j] = hh; l[j] = (__bf16)(st[i][j] - (float)hh); }
+      // 16-byte chunk c = k / 8 of row r lives at chunk c ^ (r & 15): ds_read_b128 of a fragment column is then conflict-free
+      // for the hardware's 16-lane groups (which mix lanes of two neighbouring chunks), and these 8-byte stores stay so too
+      const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
+      *(bf16x4*)(dh + o) = h;
+      *(bf16x4*)(dl + o) = l;
+    }
+  };
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 >= p.groups) return;
+  load_group(g0, st0);
+  store_group(0, st0);
+  if (g0 + gs < p.groups) load_group(g0 + gs, st0);
+  __syncthreads();
+  // Software pipeline: iteration `it` multiplies group g out of LDS buffer it & 1 while the epilogue of the PREVIOUS group
+  // (accumulators `pacc`) runs in the shadow of those MFMAs -- both are in one basic block (no row guards: M is a multiple of
+  // WS_ROWS), so the scheduler can pair every MFMA with the VALU / store work of the other stage.  Then group g + gs is staged
+  // from register set (it + 1) & 1.
+  const float* __restrict__ twg2 = twg;
+  auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
+    float* qsw = qs + (par * WS_NW + wave) * WS_ROWS;
+    f32x4 bq[WS_CB], twq[WS_CB];
+#pragma unroll
+    for (int cb = 0; cb < WS_CB; ++cb) {
+      bq[cb] = *(const f32x4*)&bg[ncol0 + 16 * cb + 4 * lq];
+      twq[cb] = *(const f32x4*)&twg2[ncol0 + 16 * cb + 4 * lq];
+    }
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      const int m = g * WS_ROWS + 16 * s + li;
+      float part = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) {
+        f32x4 v = acc[s][cb] + bq[cb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+#ifndef WS_LAB_NO_STORE
+        *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+#else
+        if (v[0] == 12345.678f) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+#endif
+        part += (v[0] * twq[cb][0] + v[1] * twq[cb][1]) + (v[2] * twq[cb][2] + v[3] * twq[cb][3]);
+        // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
+        nbs[(par * WS_ROWS + 16 * s + li) * 64 + 4 * WS_CB * wave + 4 * cb + lq] =
+            (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+      }
+      if (TQ) {
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (lq == 0) qsw[16 * s + li] = part;
+      }
+    }
+  };
+  auto finish = [&](int g, int par) __attribute__((always_inline)) {   // after the barrier that follows epilogue(g)
+    if (tid < WS_ROWS * 8) {                         // thread (row, word): eight nibbles -> one 32-column mask word
+      const int row = tid >> 3, wd = tid & 7, m = g * WS_ROWS + row;
+      const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * 64 + 8 * wd);
+      const unsigned int d0 = nb[0], d1 = nb[1];
+      const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
+      const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
+      p.mb[z0 * p.mb_s0 + z1 * p.mb_s1 + (long)m * p.mb_g + wd] = lo16 | (hi16 << 16);
+    }
+    if (TQ && tid < WS_ROWS) {                       // eight column-slice partial sums per row, fixed order
+      const int m = g * WS_ROWS + tid;
+      const float* q8 = qs + par * WS_NW * WS_ROWS + tid;
+      float a = tbias;
+#pragma unroll
+      for (int w = 0; w < WS_NW; ++w) a += q8[w * WS_ROWS];
+      p.tq[z0 * p.tq_s0 + z1 * p.tq_s1 + (long)m * p.tq_sm] = a;
+    }
+  };
+
+  f32x4 pacc[WS_SUB][WS_CB];
+  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first) __attribute__((always_inline)) {
+    const int buf = it & 1;
+    const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    const __bf16* al = ah + WS_ROWS * WS_PITCH;
+    f32x4 acc[WS_SUB][WS_CB];
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const int o = (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3);
+        const bf16x8 fah = *(const bf16x8*)&ah[o], fal = *(const bf16x8*)&al[o];
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) {             // operands swapped: D[n][m], lane holds C[m = li][n = 4 lq + r]
+#ifdef WS_LAB_NO_MFMA
+          asm volatile("" :: "v"(fah), "v"(fal), "v"(bl[cb][ks]), "v"(bh[cb][ks]));
+#else
+          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cb][ks], fah, acc[s][cb], 0, 0, 0);
+          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fal, acc[s][cb], 0, 0, 0);
+          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah, acc[s][cb], 0, 0, 0);
+#endif
+        }
+      }
+    }
+    if (!first) epilogue(pacc, g - gs, (it - 1) & 1);
+    if (g + gs < p.groups) store_group(buf ^ 1, stn);
+    if (g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+    __syncthreads();
+    if (!first) finish(g - gs, (it - 1) & 1);
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) pacc[s][cb] = acc[s][cb];
+  };
+  int g = g0, it = 0;
+  iteration(g, it, st0, true);
+  g += gs; ++it;
+  while (g < p.groups) {
+    iteration(g, it, st0, false);
+    g += gs; ++it;
+  }
+  // drain: the last group's epilogue
+  epilogue(pacc, g - gs, (it - 1) & 1);
+  __syncthreads();
+  finish(g - gs, (it - 1) & 1);
+}
+
+// host: does the launch qualify?  (split-bf16 precision, K = N = 256, 16-byte aligned operands)
+static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
+  if (K != WS_K || N != WS_N || p.M < 1024 || (p.M % WS_ROWS) || !p.mb) return false;
+  if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
+  if (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || !aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
+  if (!aligned16(p.Y) || (p.y_pitch & 3) || (p.y_s0 & 3) || (p.y_s1 & 3)) return false;
+  if (p.tq && (!aligned16(p.tw) || (p.tw_s0 & 3) || (p.tw_s1 & 3))) return false;
+  return true;
+}
+
+static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
+  p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
+  // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems
+  int per_z = (256 + nz - 1) / nz;
+  if (per_z < 1) per_z = 1;
+  if (per_z > p.groups) per_z = p.groups;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_fwd_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_fwd_lds_bytes());
+    if (e != hipSuccess) return e;
+    raised = true;
+  }
+  if (p.tq) hipLaunchKernelGGL(ws_fwd_kernel<true>, dim3(per_z, 1, nz), dim3(WS_NT), ws_fwd_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_fwd_kernel<false>, dim3(per_z, 1, nz), dim3(WS_NT), ws_fwd_lds_bytes(), st, p);
+  return hipGetLastError();
+}
+
+}  // namespace orl
