@@ -374,6 +374,33 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   if (maskH && maskH->bits && bits_live.count(maskH->bits) && ncols == maskH->pitch && aligned16(maskH->p) && (maskH->pitch & 3) == 0) {
     p.aux_bits = maskH->bits; p.xb_s0 = maskH->brs; p.xb_s1 = maskH->bcs; p.xb_g = maskH->bg;
   }
+  // weight-stationary fused kernel (csrc/ws_gemm.h): top-layer dgrad from mask bits + layer-0 weight gradient, nothing stored
+  if (w0_X && w0_slabs && !store_dx && maskH && dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar &&
+      this->cfg.precision == 1 && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
+      ncols == in && (long)M * nz >= 40000) {
+    WsDgradP w;
+    memset(&w, 0, sizeof(w));
+    w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
+    w.xbits = maskH->bits; w.xb_s0 = maskH->brs; w.xb_s1 = maskH->bcs; w.xb_g = maskH->bg;
+    w.dq = dy.rowv.p; w.dq_s0 = dy.rowv.rs; w.dq_s1 = dy.rowv.cs; w.dq_sm = dy.rowv.pitch;
+    w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    w.X = w0_X->p; w.x_s0 = w0_X->rs; w.x_s1 = w0_X->cs; w.x_pitch = w0_X->pitch; w.in0 = l.layer_in(0);
+    float* g = grads + nr.g_off;
+    w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
+    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
+    w.M = M; w.nz1 = nr.nz1;
+    if (ws_dgrad_supported(w, out, in)) {
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab);
+      prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
+                 nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (w0_X->pitch + 1) + 4.0 * per_z * in * (l.layer_in(0) + 1)));
+      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
+      *w0_slabs = per_z;
+      return 0;
+    }
+  }
   if (w0_X && w0_slabs && maskH && layer == 1 && col0 == 0 && !l.ens && !force_scalar) {
     // fuse the layer-0 weight / bias gradient into this launch's epilogue (one slab per row tile)
     const int slabs = w0_fused_slabs(p, nz, l.layer_in(0), w0_X->pitch, w0_X->p, w0_X->rs, w0_X->cs, max_slab);

@@ -254,4 +254,217 @@ static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   return hipGetLastError();
 }
 
+
+// =====================================================================================================================
+// ws_dgrad_w0: backward through the top hidden layer of a single-output net, fused with the layer-0 weight gradient.
+//
+//   dz0[m][n] = 1[h0[m][n] > 0] * dq[m] * sum_k 1[h1[m][k] > 0] * (w_tail[k] * W1[k][n])          (reference: autograd of
+//   dW0[n][c] = sum_m dz0[m][n] * X[m][c],   db0[n] = sum_m dz0[m][n]                               critic_module.py:17-28)
+//
+// Same weight-stationary structure as ws_fwd: wave w keeps B'[n][k] = w_tail[k] * W1[k][n] for its 32 columns n and all
+// 256 k as split-bf16 fragments in registers.  The A operand is the ReLU mask of h1, i.e. exactly 0 / 1 in bf16: it is
+// expanded from the packed mask bits straight into the swizzled LDS image (1 KB of HBM per 32 rows instead of 32 KB) and
+// needs no lo plane, so a block costs 2 MFMAs instead of 3.  The accumulators come out as D[m][n] with four consecutive rows
+// per lane -- which is precisely the B-operand layout of v_mfma_f32_16x16x16_bf16 -- so after the dq scale and the h0 mask
+// they are fed, still in registers, into dW0^T[c][n] += X^T[c][m] dz0[m][n] (X^T staged in LDS as split bf16, column
+// `in0` = 1 gives db0).  dW0 accumulates in 16 VGPRs over ALL row groups of the workgroup and is written once, as one
+// split-K slab per workgroup.  dz0 itself never exists outside registers.
+// =====================================================================================================================
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct WsDgradP {
+  const unsigned int* abits; long ab_s0, ab_s1; int ab_g;     // mask words of the top hidden activation (K = 256 columns)
+  const unsigned int* xbits; long xb_s0, xb_s1; int xb_g;     // mask words of the layer-0 activation (N = 256 columns)
+  const float* dq; long dq_s0, dq_s1, dq_sm;                   // dLoss/dq per row
+  const float* wt; long wt_s0, wt_s1;                          // w_tail [256]
+  const float* W; long w_s0, w_s1;                             // W1 (out = k, in = n) row-major [256][256]
+  const float* X; long x_s0, x_s1; int x_pitch, in0;           // layer-0 input rows [M][x_pitch], in0 + 1 <= 32
+  float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256])
+  int M, nz1, groups;
+};
+static constexpr size_t ws_dgrad_lds_bytes() { return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WS_ROWS * 2; }
+
+__global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
+  static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
+  __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][m = 32]: X^T of the row group
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const unsigned int* __restrict__ xb = p.xbits + z0 * p.xb_s0 + z1 * p.xb_s1;
+  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
+  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const int ncol0 = 32 * wave;
+
+  // resident B' fragments: lane (li, lq) supplies B'[k = 32 ks + 8 lq + j][n = ncol0 + 16 cb + li] = w_tail[k] * W1[k][n]
+  bf16x8 bh[2][8], bl[2][8];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int n = ncol0 + 16 * cb + li, k0 = 32 * ks + 8 * lq;
+      const f32x4 t0 = *(const f32x4*)&wtg[k0], t1 = *(const f32x4*)&wtg[k0 + 4];
+      f32x4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = t0[j] * Wg[(long)(k0 + j) * WS_N + n]; b[j] = t1[j] * Wg[(long)(k0 + 4 + j) * WS_N + n]; }
+      ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
+    }
+  // zero both X^T images once (rows c >= x_pitch are never written again)
+  for (int e = tid; e < 2 * 2 * 32 * WS_ROWS / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
+  __syncthreads();
+
+  // ---- staging of one row group: thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
+  unsigned int sm_word;
+  float sx[2];
+  const int xe = WS_ROWS * p.x_pitch;                                // X elements of a row group (<= 1024)
+  auto load_group = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + WS_NT * i;
+      sx[i] = e < xe ? Xg[(long)g * xe + e] : 0.f;
+    }
+  };
+  auto store_group = [&](int buf) __attribute__((always_inline)) {
+    const int r = tid >> 4, hw = tid & 15;
+    const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
+    u32x4 c0, c1;                                                    // 16 bf16 values: 1.0 = 0x3F80 where the bit is set
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int y0 = (bits >> (2 * j)) & 3u, y1 = (bits >> (8 + 2 * j)) & 3u;
+      c0[j] = ((y0 & 1u) | ((y0 >> 1) << 16)) * 0x3F80u;
+      c1[j] = ((y1 & 1u) | ((y1 >> 1) << 16)) * 0x3F80u;
+    }
+    __bf16* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
+    *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
+    *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
+    __bf16* xt = XT + (long)buf * 2 * 32 * WS_ROWS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + WS_NT * i;
+      if (e < xe) {
+        const int rr = e / p.x_pitch, c = e - rr * p.x_pitch;
+        const float x = (c == p.in0) ? 1.0f : sx[i];
+        const __bf16 hh = (__bf16)x;
+        xt[c * WS_ROWS + rr] = hh;
+        xt[32 * WS_ROWS + c * WS_ROWS + rr] = (__bf16)(x - (float)hh);
+      }
+    }
+  };
+
+  f32x4 d2[2][2];                                                    // dW0^T blocks [c block][cb], accumulated over all groups
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) d2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 < p.groups) {
+    load_group(g0);
+    store_group(0);
+    if (g0 + gs < p.groups) load_group(g0 + gs);
+  }
+  __syncthreads();
+  int it = 0;
+  for (int g = g0; g < p.groups; g += gs, ++it) {
+    const int buf = it & 1;
+    // epilogue operands of this group: dq of the lane's 4 rows per 16-row block, and the h0 mask word of those rows
+    f32x4 dq4[WS_SUB];
+    unsigned int xw[WS_SUB][4];
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      const int m = g * WS_ROWS + 16 * s + 4 * lq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { dq4[s][r] = dqg[(long)(m + r) * p.dq_sm]; xw[s][r] = xb[(long)(m + r) * p.xb_g + wave]; }
+    }
+    const __bf16* ah = Ah + (long)buf * WS_ROWS * WS_PITCH;
+    f32x4 acc[WS_SUB][2];
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const bf16x8 fa = *(const bf16x8*)&ah[(16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3)];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {               // D[m][n]: lane holds rows 4 lq + r of column li
+          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bl[cb][ks], acc[s][cb], 0, 0, 0);
+          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bh[cb][ks], acc[s][cb], 0, 0, 0);
+        }
+      }
+    }
+    // dz0 block -> (hi, lo) bf16 B operand of the 16x16x16 MFMA; A operand = X^T rows c, columns m = 16 s + 4 lq ..
+    const __bf16* xth = XT + (long)buf * 2 * 32 * WS_ROWS;
+    const __bf16* xtl = xth + 32 * WS_ROWS;
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      s16x4 xh[2], xl[2];
+#pragma unroll
+      for (int cbk = 0; cbk < 2; ++cbk) {
+        xh[cbk] = *(const s16x4*)&xth[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+        xl[cbk] = *(const s16x4*)&xtl[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        bf16x4 zh, zl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4[s][r] : 0.f;
+          const __bf16 hh = (__bf16)v;
+          zh[r] = hh; zl[r] = (__bf16)(v - (float)hh);
+        }
+        const s16x4 bzh = *(const s16x4*)&zh, bzl = *(const s16x4*)&zl;
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl[cbk], bzh, d2[cbk][cb], 0, 0, 0);
+          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzl, d2[cbk][cb], 0, 0, 0);
+          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzh, d2[cbk][cb], 0, 0, 0);
+        }
+      }
+    }
+    if (g + gs < p.groups) store_group(buf ^ 1);
+    if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
+    __syncthreads();
+  }
+  // one slab per workgroup: lane (li, lq) holds dW0^T[c = 16 cbk + 4 lq + r][n = ncol0 + 16 cb + li]
+  float* wo = p.w0_out + z0 * p.o_s0 + z1 * p.o_s1 + (long)blockIdx.x * p.o_ks;
+  float* bo = p.b0_out + z0 * p.o_s0 + z1 * p.ob_s1 + (long)blockIdx.x * p.o_ks;
+#pragma unroll
+  for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * cbk + 4 * lq + r, n = ncol0 + 16 * cb + li;
+        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r];
+        else if (c == p.in0) bo[n] = d2[cbk][cb][r];
+      }
+}
+
+static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
+  if (K != WS_K || N != WS_N || p.M < 1024 || (p.M % WS_ROWS)) return false;
+  if (!p.abits || !p.xbits || p.ab_g != 8 || p.xb_g != 8) return false;
+  if (p.in0 + 1 > 32 || p.in0 >= p.x_pitch || p.x_pitch > 32 || WS_ROWS * p.x_pitch > 2 * WS_NT) return false;
+  if (!aligned16(p.wt) || (p.wt_s0 & 3) || (p.wt_s1 & 3)) return false;
+  return true;
+}
+// blocks per problem (= split-K slabs written per problem)
+static inline int ws_dgrad_blocks(int M, int nz, int max_slab) {
+  const int groups = M / WS_ROWS;
+  int per_z = (256 + nz - 1) / nz;
+  if (per_z > groups) per_z = groups;
+  if (per_z > max_slab) per_z = max_slab;
+  return per_z < 1 ? 1 : per_z;
+}
+static inline hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st) {
+  p.groups = p.M / WS_ROWS;
+  hipLaunchKernelGGL(ws_dgrad_w0_kernel, dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
+  return hipGetLastError();
+}
+
 }  // namespace orl
