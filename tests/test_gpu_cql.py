@@ -135,6 +135,31 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
         eng.close()
 
 
+def test_cql_weight_stationary_kernels_match_tiled_kernels():
+    """Split-bf16, full size: with 4 runs per engine the 256x256 critic layers go through the weight-stationary kernels
+    (csrc/ws_gemm.h: forward with fused tail + mask bits, top-layer dgrad from mask bits fused with the layer-0 weight
+    gradient); a single-run engine takes the tiled GEMM path for the same math.  Same inputs -> losses and updated
+    critic parameters must agree to rounding (both are 3-product bf16 splits with fp32 accumulation)."""
+    case = "cql_halfcheetah"
+    R = 4
+    eng4, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
+    eng1, _, _, _, _ = make_engine(case, n_runs=1, precision=1)
+    try:
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            m4 = eng4.step(lead(b, R), lead(noise_list(n), R))
+            m1 = eng1.step(lead(b), lead(noise_list(n)))[0]
+            for r in range(R):
+                assert rel_err(m4[r], m1, floor=1e-2) < 2e-5, (k, r, m4[r], m1)
+        for nm in ("critic1", "critic2"):
+            a, b1 = eng4.get_net(R - 1, NETS[nm]), eng1.get_net(0, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < 3e-6, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < 2e-3, (nm, pn)
+    finally:
+        eng4.close(); eng1.close()
+
+
 def test_cql_learn_n_device_sampling_runs_and_is_finite():
     from offlinerlkit import _engine
     case = "cql_tiny"
