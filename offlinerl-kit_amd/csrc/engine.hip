@@ -284,7 +284,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
   if (epi == E_BIAS_RELU && this->cfg.precision == 1 && !force_scalar && !l.ens && !use_fused && in_row0 == 0 && in_rows == in &&
-      Y.bits && Y.pitch == out && (long)M * nz >= 40000) {
+      Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
     w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch;

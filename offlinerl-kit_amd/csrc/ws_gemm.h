@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
 // host: does the launch qualify?  (split-bf16 precision, K = N = 256, 16-byte aligned operands)
 static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
-  if (K != WS_K || N != WS_N || p.M < 1024 || (p.M % WS_ROWS) || !p.mb) return false;
+  if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.mb) return false;
   if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
   if (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || !aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
   if (!aligned16(p.Y) || (p.y_pitch & 3) || (p.y_s0 & 3) || (p.y_s1 & 3)) return false;
