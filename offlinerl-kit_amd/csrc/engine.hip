@@ -401,6 +401,27 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
       return 0;
     }
   }
+  // same kernel, storing variant (no layer-0 gradient): e.g. the critic backward of the actor loss, where dz0 feeds dL/da
+  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !l.ens && !force_scalar && this->cfg.precision == 1 && p.aux_bits &&
+      dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= 4096) {
+    WsDgradP w;
+    memset(&w, 0, sizeof(w));
+    w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
+    w.xbits = maskH->bits; w.xb_s0 = maskH->brs; w.xb_s1 = maskH->bcs; w.xb_g = maskH->bg;
+    w.dq = dy.rowv.p; w.dq_s0 = dy.rowv.rs; w.dq_s1 = dy.rowv.cs; w.dq_sm = dy.rowv.pitch;
+    w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
+    w.M = M; w.nz1 = nr.nz1;
+    if (ws_dgrad_supported(w, out, in)) {
+      const int per_z = ws_dgrad_blocks(M, nz, 1 << 20);
+      prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
+      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
+      return 0;
+    }
+  }
   if (w0_X && w0_slabs && maskH && layer == 1 && col0 == 0 && !l.ens && !force_scalar) {
     // fuse the layer-0 weight / bias gradient into this launch's epilogue (one slab per row tile)
     const int slabs = w0_fused_slabs(p, nz, l.layer_in(0), w0_X->pitch, w0_X->p, w0_X->rs, w0_X->cs, max_slab);

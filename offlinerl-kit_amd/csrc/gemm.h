@@ -808,8 +808,7 @@ static inline int tq_fused_parts(int cfg, const GemmP& p, const float* tail_w, l
 
 // Will a forward launch on `cfg` emit packed mask bits (GemmP::mb_out)?  Same conditions as the fused tail.
 static inline bool mb_supported(int cfg, const GemmP& p) {
-  const int TN = cfg == CFG_SQ8 ? CfgSq8::TN : (cfg == CFG_BIG ? CfgBig::TN : 0);
-  if (!TN || (p.N & 31)) return false;
+  if (cfg == CFG_TALL || (p.N & 31)) return false;        // every other tile stages its epilogue through LDS with >= 8 lanes per row
   if (!aligned16(p.C) || (p.c_sr & 3) || (p.c_s0 & 3) || (p.c_s1 & 3) || p.c_sn != 1) return false;
   return aligned16(p.bias.p) && !(p.bias.s0 & 3) && !(p.bias.s1 & 3);
 }

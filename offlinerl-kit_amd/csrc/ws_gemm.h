@@ -279,11 +279,13 @@ struct WsDgradP {
   const float* wt; long wt_s0, wt_s1;                          // w_tail [256]
   const float* W; long w_s0, w_s1;                             // W1 (out = k, in = n) row-major [256][256]
   const float* X; long x_s0, x_s1; int x_pitch, in0;           // layer-0 input rows [M][x_pitch], in0 + 1 <= 32
-  float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256])
+  float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
+  float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
   int M, nz1, groups;
 };
 static constexpr size_t ws_dgrad_lds_bytes() { return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WS_ROWS * 2; }
 
+template <bool W0, bool STORE>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
@@ -313,19 +315,22 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
     }
   // zero both X^T images once (rows c >= x_pitch are never written again)
-  for (int e = tid; e < 2 * 2 * 32 * WS_ROWS / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
+  if (W0) for (int e = tid; e < 2 * 2 * 32 * WS_ROWS / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
   __syncthreads();
 
   // ---- staging of one row group: thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
   unsigned int sm_word;
   float sx[2];
-  const int xe = WS_ROWS * p.x_pitch;                                // X elements of a row group (<= 1024)
+  const int xe = W0 ? WS_ROWS * p.x_pitch : 0;                       // X elements of a row group (<= 1024)
+  float* __restrict__ Cg = STORE ? p.C + z0 * p.c_s0 + z1 * p.c_s1 : nullptr;
   auto load_group = [&](int g) __attribute__((always_inline)) {
     sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    if (W0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + WS_NT * i;
-      sx[i] = e < xe ? Xg[(long)g * xe + e] : 0.f;
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + WS_NT * i;
+        sx[i] = e < xe ? Xg[(long)g * xe + e] : 0.f;
+      }
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + WS_NT * i;
-      if (e < xe) {
+      if (W0 && e < xe) {
         const int rr = e / p.x_pitch, c = e - rr * p.x_pitch;
         const float x = (c == p.in0) ? 1.0f : sx[i];
         const __bf16 hh = (__bf16)x;
@@ -404,10 +409,12 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
       s16x4 xh[2], xl[2];
+      if (W0) {
 #pragma unroll
-      for (int cbk = 0; cbk < 2; ++cbk) {
-        xh[cbk] = *(const s16x4*)&xth[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
-        xl[cbk] = *(const s16x4*)&xtl[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+        for (int cbk = 0; cbk < 2; ++cbk) {
+          xh[cbk] = *(const s16x4*)&xth[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+          xl[cbk] = *(const s16x4*)&xtl[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+        }
       }
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
@@ -415,12 +422,13 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4[s][r] : 0.f;
+          if (STORE) Cg[(long)(g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + 16 * cb + li] = v;
           const __bf16 hh = (__bf16)v;
           zh[r] = hh; zl[r] = (__bf16)(v - (float)hh);
         }
         const s16x4 bzh = *(const s16x4*)&zh, bzl = *(const s16x4*)&zl;
 #pragma unroll
-        for (int cbk = 0; cbk < 2; ++cbk) {
+        for (int cbk = 0; cbk < 2 && W0; ++cbk) {
           d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl[cbk], bzh, d2[cbk][cb], 0, 0, 0);
           d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzl, d2[cbk][cb], 0, 0, 0);
           d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzh, d2[cbk][cb], 0, 0, 0);
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
     __syncthreads();
   }
+  if (!W0) return;
   // one slab per workgroup: lane (li, lq) holds dW0^T[c = 16 cbk + 4 lq + r][n = ncol0 + 16 cb + li]
   float* wo = p.w0_out + z0 * p.o_s0 + z1 * p.o_s1 + (long)blockIdx.x * p.o_ks;
   float* bo = p.b0_out + z0 * p.o_s0 + z1 * p.ob_s1 + (long)blockIdx.x * p.o_ks;
@@ -447,9 +456,10 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 }
 
 static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
-  if (K != WS_K || N != WS_N || p.M < 1024 || (p.M % WS_ROWS)) return false;
+  if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS)) return false;
   if (!p.abits || !p.xbits || p.ab_g != 8 || p.xb_g != 8) return false;
-  if (p.in0 + 1 > 32 || p.in0 >= p.x_pitch || p.x_pitch > 32 || WS_ROWS * p.x_pitch > 2 * WS_NT) return false;
+  if (p.w0_out && (p.in0 + 1 > 32 || p.in0 >= p.x_pitch || p.x_pitch > 32 || WS_ROWS * p.x_pitch > 2 * WS_NT)) return false;
+  if (!p.w0_out && !p.C) return false;
   if (!aligned16(p.wt) || (p.wt_s0 & 3) || (p.wt_s1 & 3)) return false;
   return true;
 }
@@ -463,7 +473,8 @@ static inline int ws_dgrad_blocks(int M, int nz, int max_slab) {
 }
 static inline hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
-  hipLaunchKernelGGL(ws_dgrad_w0_kernel, dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
+  if (p.w0_out) hipLaunchKernelGGL((ws_dgrad_w0_kernel<true, false>), dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL((ws_dgrad_w0_kernel<false, true>), dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
   return hipGetLastError();
 }
 
