@@ -156,7 +156,8 @@ struct Engine {
 
   // launch helpers (enqueue on stream)
   int linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH, const char* tag,
-                 int in_row0 = 0, int in_rows = -1, const Mat* tail_out = nullptr, bool* tail_fused = nullptr);
+                 int in_row0 = 0, int in_rows = -1, const Mat* tail_out = nullptr, bool* tail_fused = nullptr,
+                 const Mat* fuse_X0 = nullptr, const char* tag0 = nullptr);
   int tq_scratch_nets = 2;
   int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag,
                    const Mat* w0_X = nullptr, bool store_dx = true, int* w0_slabs = nullptr);

@@ -262,8 +262,10 @@ struct DY {
   static DY virt(const Mat& H, const Mat& dq) { DY d; d.rank1 = true; d.m = H; d.rowv = dq; return d; }
 };
 
+// fuse_X0 (layer == 1 only): X = hs[0] has not been computed yet; it is relu(fuse_X0 W0^T + b0).  The weight-stationary kernel
+// produces it inside this launch (stores it to X for the backward pass); any other path first runs layer 0 on its own.
 int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH,
-                       const char* tag, int in_row0, int in_rows, const Mat* tail_out, bool* tail_fused) {
+                       const char* tag, int in_row0, int in_rows, const Mat* tail_out, bool* tail_fused, const Mat* fuse_X0, const char* tag0) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
@@ -299,8 +301,25 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       w.tb = nr.base + l.b_off[l.L]; w.tb_s0 = nr.rs; w.tb_s1 = l.b_ms[l.L];
       w.tq = tail_out->p; w.tq_s0 = tail_out->rs; w.tq_s1 = tail_out->cs; w.tq_sm = tail_out->pitch;
     }
-    if (ws_fwd_supported(w, in, out)) {
-      prof_begin(tag, 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz, 4.0 * nz * ((double)M * in + (double)out * in + (double)M * out));
+    const bool ws_ok = ws_fwd_supported(w, in, out);
+    bool fused0 = false;
+    if (ws_ok && fuse_X0 && layer == 1 && X.bits && X.pitch == in) {
+      w.X0 = fuse_X0->p; w.x0_s0 = fuse_X0->rs; w.x0_s1 = fuse_X0->cs; w.x0_pitch = fuse_X0->pitch; w.in0 = l.layer_in(0);
+      w.W0 = nr.base + l.w_off[0]; w.w0_s0 = nr.rs; w.w0_s1 = l.w_ms[0];
+      w.b0 = nr.base + l.b_off[0]; w.b0_s0 = nr.rs; w.b0_s1 = l.b_ms[0];
+      w.mb0 = X.bits; w.mb0_s0 = X.brs; w.mb0_s1 = X.bcs; w.mb0_g = X.bg;
+      fused0 = ws_fwd01_supported(w) && aligned16(fuse_X0->p);
+      if (!fused0) w.X0 = nullptr;
+    }
+    if (fuse_X0 && !fused0) {      // layer 0 on its own, then this layer
+      if (linear_fwd(*fuse_X0, M, nr, 0, X, E_BIAS_RELU, nullptr, tag0 ? tag0 : tag)) return -1;
+      fuse_X0 = nullptr;
+    }
+    if (ws_ok) {
+      const double f0 = fused0 ? 2.0 * M * (double)in * (w.in0 + 1) * nz : 0.0;
+      prof_begin(tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
+                 4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (double)M * in + (double)out * in + (double)M * out));
+      if (fused0) bits_live.insert(X.bits);
       hipError_t err = launch_ws_fwd(w, nz, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
@@ -308,6 +327,9 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       if (tail_fused) *tail_fused = want_tail;
       return 0;
     }
+  }
+  if (fuse_X0) {                   // no fused path: layer 0 first
+    if (linear_fwd(*fuse_X0, M, nr, 0, X, E_BIAS_RELU, nullptr, tag0 ? tag0 : tag)) return -1;
   }
   if (Y.bits) {
     if (epi == E_BIAS_RELU && !force_scalar && out == Y.pitch && mb_supported(cfg, p)) {
@@ -583,9 +605,11 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     if (prof_on) prof.pop_back();
   }
   bool tail_done = false;
-  for (int i = 0; i < Ln; ++i)
+  for (int i = 0; i < Ln; ++i) {
+    if (i == 0 && Ln >= 2) continue;         // layer 0 is issued together with layer 1 (fused into it when the ws kernel applies)
     if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str(), 0, -1,
-                   i == Ln - 1 ? &out : nullptr, i == Ln - 1 ? &tail_done : nullptr)) return -1;
+                   i == Ln - 1 ? &out : nullptr, i == Ln - 1 ? &tail_done : nullptr, i == 1 ? &X : nullptr, (t + ".fwd0").c_str())) return -1;
+  }
   if (tail_done) return 0;                 // single-output tail folded into the last hidden layer's epilogue
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
 }

@@ -36,6 +36,12 @@ struct WsFwdP {
   const float* tb; long tb_s0, tb_s1;
   float* tq; long tq_s0, tq_s1, tq_sm;
   int M, nz1, groups;                                   // groups = ceil(M / WS_ROWS)
+  // fused first layer (template L0): X is then PRODUCED here as relu(X0 W0^T + b0) from the narrow input rows X0 (in0 + 1 <= 32 columns
+  // incl. the bias as a ones column), stored to `X` for the backward pass, and handed to the second layer through LDS only
+  const float* X0; long x0_s0, x0_s1; int x0_pitch, in0;
+  const float* W0; long w0_s0, w0_s1;                   // (256, in0) row-major
+  const float* b0; long b0_s0, b0_s1;
+  unsigned int* mb0; long mb0_s0, mb0_s1; int mb0_g;    // packed ReLU mask of X (= h0)
 };
 
 #ifndef WS_WAVES
@@ -45,7 +51,9 @@ enum { WS_ROWS = 32, WS_K = 256, WS_N = 256, WS_PITCH = WS_K, WS_NW = WS_WAVES, 
 enum { WS_SUB = WS_ROWS / 16, WS_LD = WS_ROWS * WS_K / 4 / WS_NT };   // 16-row blocks per group; float4 loads per thread per group
 // LDS: A image [2 buffers][hi, lo][WS_ROWS][256] bf16 (swizzled) + tail partial sums [2][WS_NW waves][WS_ROWS] floats
 //      + ReLU-mask nibbles [2][WS_ROWS][64] bytes
-static constexpr size_t ws_fwd_lds_bytes() { return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * 64; }
+static constexpr size_t ws_fwd_lds_bytes(bool l0 = false) {
+  return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * 64 + (l0 ? sizeof(float) * 2 * WS_ROWS * 32 + 2 * WS_ROWS * 64 : 0);
+}
 
 __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
 #pragma unroll
@@ -55,12 +63,14 @@ __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16
   }
 }
 
-template <bool TQ>
+template <bool TQ, bool L0>
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
   float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
   unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
+  float* Xl = (float*)(nbs + 2 * WS_ROWS * 64);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
+  unsigned char* nbs0 = (unsigned char*)(Xl + 2 * WS_ROWS * 32);         // L0: mask nibbles of the produced h0
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
@@ -68,6 +78,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
   float* __restrict__ Yg = p.Y + z0 * p.y_s0 + z1 * p.y_s1;
   const int ncol0 = 16 * WS_CB * wave;
+  float* __restrict__ Y0g = L0 ? const_cast<float*>(Xg) : nullptr;       // L0: h0 is written where the plain kernel reads it
+  const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
 
   // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
   bf16x8 bh[WS_CB][8], bl[WS_CB][8];
@@ -78,6 +90,24 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       const float* src = Wg + (long)(ncol0 + 16 * cb + li) * WS_K + 32 * ks + 8 * lq;
       ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
     }
+  // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
+  bf16x8 b0h[WS_CB], b0l[WS_CB];
+  if (L0) {
+    const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
+    const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
+#pragma unroll
+    for (int cb = 0; cb < WS_CB; ++cb) {
+      const int n = ncol0 + 16 * cb + li;
+      f32x4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 8 * lq + j, k1 = k0 + 4;
+        a[j] = k0 < p.in0 ? W0g[(long)n * p.in0 + k0] : (k0 == p.in0 ? b0g[n] : 0.f);
+        b[j] = k1 < p.in0 ? W0g[(long)n * p.in0 + k1] : (k1 == p.in0 ? b0g[n] : 0.f);
+      }
+      ws_split8(a, b, b0h[cb], b0l[cb]);
+    }
+  }
   // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r are re-read per row group (L1 hits) rather than
   // held in 16 VGPRs next to the 128 VGPRs of resident B fragments
   const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
@@ -111,12 +141,84 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     }
   };
 
+  // ---- L0: narrow-input staging (two elements per thread) and the producer of one h0 row group ----
+  const int xe = L0 ? WS_ROWS * p.x0_pitch : 0;
+  int xr[2], xc[2];
+  float sx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0; }
+  auto loadX = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = e < xe ? X0g[(long)g * xe + e] : 0.f; }
+  };
+  auto storeX = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (tid + WS_NT * i < xe) Xl[(buf * WS_ROWS + xr[i]) * 32 + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];
+  };
+  // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
+  auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
+    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      const int r = 16 * s + li;
+      const float* xrow = Xl + (xbuf * WS_ROWS + r) * 32 + 8 * lq;
+      bf16x8 xah, xal;
+      ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+      const long m = (long)g * WS_ROWS + r;
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) {
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+        const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
+        *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)v[j]; h[j] = hh; l[j] = (__bf16)(v[j] - (float)hh); }
+        const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
+        *(bf16x4*)(dh + o) = h;
+        *(bf16x4*)(dl + o) = l;
+        nbs0[(par * WS_ROWS + r) * 64 + (k >> 2)] =
+            (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+      }
+    }
+  };
+  auto finish0 = [&](int g, int par) __attribute__((always_inline)) {  // after the barrier that follows produce(g): pack the h0 mask
+    if (tid < WS_ROWS * 8) {
+      const int row = tid >> 3, wd = tid & 7;
+      const unsigned int* nb = (const unsigned int*)(nbs0 + (par * WS_ROWS + row) * 64 + 8 * wd);
+      const unsigned int d0 = nb[0], d1 = nb[1];
+      const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
+      const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
+      p.mb0[z0 * p.mb0_s0 + z1 * p.mb0_s1 + ((long)g * WS_ROWS + row) * p.mb0_g + wd] = lo16 | (hi16 << 16);
+    }
+  };
+
   const int g0 = blockIdx.x, gs = gridDim.x;
   if (g0 >= p.groups) return;
-  load_group(g0, st0);
-  store_group(0, st0);
-  if (g0 + gs < p.groups) load_group(g0 + gs, st0);
-  __syncthreads();
+  if (L0) {
+    for (int e = tid; e < 2 * WS_ROWS * 32; e += WS_NT) Xl[e] = 0.f;   // columns >= x0_pitch stay zero
+    loadX(g0);
+    __syncthreads();
+    storeX(0);
+    if (g0 + gs < p.groups) loadX(g0 + gs);
+    __syncthreads();
+    produce(g0, 0, 0, 0);
+    if (g0 + gs < p.groups) storeX(1);
+    if (g0 + 2 * gs < p.groups) loadX(g0 + 2 * gs);
+    __syncthreads();
+    finish0(g0, 0);
+  } else {
+    load_group(g0, st0);
+    store_group(0, st0);
+    if (g0 + gs < p.groups) load_group(g0 + gs, st0);
+    __syncthreads();
+  }
   // Software pipeline: iteration `it` multiplies group g out of LDS buffer it & 1 while the epilogue of the PREVIOUS group
   // (accumulators `pacc`) runs in the shadow of those MFMAs -- both are in one basic block (no row guards: M is a multiple of
   // WS_ROWS), so the scheduler can pair every MFMA with the VALU / store work of the other stage.  Then group g + gs is staged
@@ -204,10 +306,18 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       }
     }
     if (!first) epilogue(pacc, g - gs, (it - 1) & 1);
-    if (g + gs < p.groups) store_group(buf ^ 1, stn);
-    if (g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+    if (L0) {
+      // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
+      if (g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
+      if (g + 2 * gs < p.groups) storeX(it & 1);
+      if (g + 3 * gs < p.groups) loadX(g + 3 * gs);
+    } else {
+      if (g + gs < p.groups) store_group(buf ^ 1, stn);
+      if (g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+    }
     __syncthreads();
     if (!first) finish(g - gs, (it - 1) & 1);
+    if (L0 && g + gs < p.groups) finish0(g + gs, (it + 1) & 1);
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
@@ -236,24 +346,39 @@ static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
   return true;
 }
 
+static inline bool ws_fwd01_supported(const WsFwdP& p) {      // extra conditions of the fused first layer
+  if (!p.X0 || !p.mb0 || p.mb0_g != 8 || p.in0 + 1 > 32 || p.in0 >= p.x0_pitch || p.x0_pitch > 32 || WS_ROWS * p.x0_pitch > 2 * WS_NT) return false;
+  return true;
+}
+
 static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
   // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems
   int per_z = (256 + nz - 1) / nz;
   if (per_z < 1) per_z = 1;
   if (per_z > p.groups) per_z = p.groups;
+  const bool l0 = p.X0 != nullptr;
+  const size_t lds = ws_fwd_lds_bytes(l0);
   static bool raised = false;
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_fwd_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_fwd_lds_bytes());
+    const int big = (int)ws_fwd_lds_bytes(true);
+    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e != hipSuccess) return e;
     raised = true;
   }
-  if (p.tq) hipLaunchKernelGGL(ws_fwd_kernel<true>, dim3(per_z, 1, nz), dim3(WS_NT), ws_fwd_lds_bytes(), st, p);
-  else hipLaunchKernelGGL(ws_fwd_kernel<false>, dim3(per_z, 1, nz), dim3(WS_NT), ws_fwd_lds_bytes(), st, p);
+  const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (l0) {
+    if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, true>), grid, block, lds, st, p);
+  } else {
+    if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, false>), grid, block, lds, st, p);
+  }
   return hipGetLastError();
 }
-
 
 // =====================================================================================================================
 // ws_dgrad_w0: backward through the top hidden layer of a single-output net, fused with the layer-0 weight gradient.

@@ -16,9 +16,17 @@ static float rnd() { rs = rs * 1664525u + 1013904223u; return ((rs >> 8) / 83886
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 1088, nz = argc > 2 ? atoi(argv[2]) : 2;
   const bool check = M * (long)nz <= 40000;
+  const bool l0 = argc > 3 && atoi(argv[3]) == 1;
+  const int xp = 24, in0 = 23;
   const long nX = (long)M * 256, nW = 65536;
   std::vector<float> hX(nX * nz), hW(nW * nz), hb(256 * nz), htw(256 * nz), htb(nz);
   for (auto& v : hX) v = rnd() > 0.f ? rnd() : 0.f;     // post-ReLU-like input
+  std::vector<float> hX0((long)M * xp * nz), hW0(256L * in0 * nz), hb0(256 * nz);
+  for (long i = 0; i < (long)M * nz; ++i) for (int c = 0; c < xp; ++c) hX0[i * xp + c] = c < in0 ? rnd() : 0.f;
+  for (auto& v : hW0) v = rnd() * 0.2f; for (auto& v : hb0) v = rnd() * 0.2f;
+  if (l0) for (int z = 0; z < nz; ++z) for (int m = 0; m < M; ++m) for (int n = 0; n < 256; ++n) {   // reference h0 (fp64 -> fp32)
+    double a = hb0[z * 256 + n]; for (int k = 0; k < in0; ++k) a += (double)hX0[((long)z * M + m) * xp + k] * hW0[((long)z * 256 + n) * in0 + k];
+    hX[z * nX + (long)m * 256 + n] = a > 0 ? (float)a : 0.f; }
   for (auto& v : hW) v = rnd() * 0.0625f;
   for (auto& v : hb) v = rnd() * 0.1f;
   for (auto& v : htw) v = rnd() * 0.0625f;
@@ -33,6 +41,12 @@ int main(int argc, char** argv) {
   p.X = dX; p.x_s1 = nX; p.x_pitch = 256; p.W = dW; p.w_s1 = nW; p.bias = db; p.b_s1 = 256; p.Y = dY; p.y_s1 = nX; p.y_pitch = 256;
   p.mb = dmb; p.mb_s1 = (long)M * 8; p.mb_g = 8; p.tw = dtw; p.tw_s1 = 256; p.tb = dtb; p.tb_s1 = 1; p.tq = dq; p.tq_s1 = M; p.tq_sm = 1;
   p.M = M; p.nz1 = nz;
+  float *dX0, *dW0, *db0; unsigned* dmb0;
+  CK(hipMalloc(&dX0, 4L * M * xp * nz)); CK(hipMalloc(&dW0, 4 * 256L * in0 * nz)); CK(hipMalloc(&db0, 4 * 256 * nz)); CK(hipMalloc(&dmb0, 4L * M * 8 * nz));
+  CK(hipMemcpy(dX0, hX0.data(), 4L * M * xp * nz, hipMemcpyHostToDevice)); CK(hipMemcpy(dW0, hW0.data(), 4 * 256L * in0 * nz, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db0, hb0.data(), 4 * 256 * nz, hipMemcpyHostToDevice));
+  if (l0) { CK(hipMemset(dX, 0, 4 * nX * nz)); p.X0 = dX0; p.x0_s1 = (long)M * xp; p.x0_pitch = xp; p.in0 = in0; p.W0 = dW0; p.w0_s1 = 256L * in0; p.b0 = db0; p.b0_s1 = 256;
+            p.mb0 = dmb0; p.mb0_s1 = (long)M * 8; p.mb0_g = 8; if (!ws_fwd01_supported(p)) { printf("l0 not supported\n"); return 1; } }
   if (!ws_fwd_supported(p, 256, 256)) { printf("not supported\n"); return 1; }
   CK(launch_ws_fwd(p, nz, 0)); CK(hipDeviceSynchronize());
   if (check) {
@@ -56,6 +70,11 @@ int main(int argc, char** argv) {
         }
         eq = std::max(eq, std::fabs(q[z * (long)M + m] - qa)); sq = std::max(sq, std::fabs(qa));
       }
+    if (l0) { std::vector<float> H0(nX * nz); std::vector<unsigned> m0((long)M * 8 * nz); CK(hipMemcpy(H0.data(), dX, 4 * nX * nz, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(m0.data(), dmb0, 4L * M * 8 * nz, hipMemcpyDeviceToHost)); double e0 = 0; long bad0 = 0;
+      for (long i = 0; i < nX * nz; ++i) { e0 = std::max(e0, (double)std::fabs(H0[i] - hX[i])); const long row = i / 256; const int n = i % 256;
+        if ((((m0[row * 8 + (n >> 5)] >> (n & 31)) & 1u) != 0) != (H0[i] > 0.f)) ++bad0; }
+      printf("fused layer 0: max|dh0|=%.3e  h0 mask bits inconsistent: %ld\n", e0, bad0); }
     printf("M=%d nz=%d  max|dY|=%.3e (scale %.3f)  max|dq|=%.3e (scale %.3f)  mask bits inconsistent with stored Y: %ld\n", M, nz, eY, sY, eq, sq, badbits);
   }
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
