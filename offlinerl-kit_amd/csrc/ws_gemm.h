@@ -353,8 +353,9 @@ static inline bool ws_fwd01_supported(const WsFwdP& p) {      // extra condition
 
 static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
-  // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems
-  int per_z = (256 + nz - 1) / nz;
+  // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems, never more workgroups than CUs
+  // (a second partial round of workgroups would double the launch time)
+  int per_z = 256 / nz;
   if (per_z < 1) per_z = 1;
   if (per_z > p.groups) per_z = p.groups;
   const bool l0 = p.X0 != nullptr;
@@ -591,7 +592,7 @@ static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
 // blocks per problem (= split-K slabs written per problem)
 static inline int ws_dgrad_blocks(int M, int nz, int max_slab) {
   const int groups = M / WS_ROWS;
-  int per_z = (256 + nz - 1) / nz;
+  int per_z = 256 / nz;
   if (per_z > groups) per_z = groups;
   if (per_z > max_slab) per_z = max_slab;
   return per_z < 1 ? 1 : per_z;
