@@ -19,11 +19,11 @@ def _strip_saved(net):
     return {k: v for k, v in net.items() if "saved_" not in k}
 
 
-def make_engine(algo, case, n_runs=1):
+def make_engine(algo, case, n_runs=1, precision=0):
     from offlinerlkit import _engine
     mod, cfg, st, batches, noises = generic_oracle_setup(algo, case)
     c = getattr(synth, f"{algo.upper()}_CASES")[case]
-    over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs)
+    over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs, precision=precision)
     if algo == "iql":
         over.update(expectile=cfg["expectile"], iql_temperature=cfg["temperature"])
     elif algo == "td3bc":
@@ -92,6 +92,33 @@ def run_case(algo, case, taps):
                 assert d.mean() < 1e-6 * (k + 1), (nm, pn, k, d.mean())
                 assert (d > tol).mean() < 2e-3, (nm, pn, k, (d > tol).mean())
     eng.close()
+
+
+def _full_size_case(algo):
+    cases = getattr(synth, f"{algo.upper()}_CASES")
+    return max(cases, key=lambda k: cases[k]["B"] * max(cases[k]["hidden"]))
+
+
+@pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
+def test_many_runs_split_bf16_follows_the_oracle(algo):
+    """16 runs per engine in split-bf16 precision: the 256-row phases of every algorithm then go through the run-batched
+    weight-stationary kernels where they apply (csrc/ws_gemm.h; the EDAC ensemble keeps the tiled kernels).  Identical inputs
+    for all runs; every run must follow the fp32 oracle at the 1e-4 gate."""
+    case = _full_size_case(algo)
+    R = 16
+    eng, mod, cfg, st, batches, noises = make_engine(algo, case, n_runs=R, precision=1)
+    keys = eng.metric_names
+    try:
+        for k, (b, n) in enumerate(zip(batches[:4], noises[:4])):
+            res, _ = mod.learn(st, cfg, b, n)
+            nl = noise_list(algo, n)
+            bb = {kk: np.stack([v] * R) for kk, v in b.items()}
+            m = eng.step(bb, [np.stack([v] * R) for v in nl] if nl is not None else [])
+            ora = np.array([res[x] for x in keys])
+            for r in (0, R // 2, R - 1):
+                assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (algo, case, k, r, m[r], ora)
+    finally:
+        eng.close()
 
 
 @pytest.mark.parametrize("case", list(synth.IQL_CASES))
