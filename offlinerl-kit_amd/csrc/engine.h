@@ -144,6 +144,7 @@ struct Engine {
   bool force_scalar = false;   // debug: disable the vector loaders
   int loss_nblk = 1;
   bool use_fused = false;      // fused multi-layer forward kernel (csrc/mlp_fused.h), opt-in with ORL_FUSED=1
+  bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
 
   ~Engine();
   int init(const orl_config& c);

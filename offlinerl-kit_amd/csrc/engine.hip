@@ -285,7 +285,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
-  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && !force_scalar && !l.ens && !use_fused && in_row0 == 0 && in_rows == in &&
+  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens && !use_fused && in_row0 == 0 && in_rows == in &&
       Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
@@ -398,8 +398,8 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   }
   // weight-stationary fused kernel (csrc/ws_gemm.h): top-layer dgrad from mask bits + layer-0 weight gradient, nothing stored
   if (w0_X && w0_slabs && !store_dx && maskH && dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar &&
-      this->cfg.precision == 1 && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
-      ncols == in && (long)M * nz >= 40000) {
+      this->cfg.precision == 1 && use_ws && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
+      ncols == in && (long)M * nz >= 4096) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
     w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
@@ -424,7 +424,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     }
   }
   // same kernel, storing variant (no layer-0 gradient): e.g. the critic backward of the actor loss, where dz0 feeds dL/da
-  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !l.ens && !force_scalar && this->cfg.precision == 1 && p.aux_bits &&
+  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !l.ens && !force_scalar && this->cfg.precision == 1 && use_ws && p.aux_bits &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= 4096) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
@@ -753,7 +753,8 @@ int Engine::init(const orl_config& c) {
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
-  { const char* f = getenv("ORL_FUSED"); use_fused = f && atoi(f) != 0; }   // opt-in: measured slower than the layer-wise kernels
+  { const char* f = getenv("ORL_FUSED"); use_fused = f && atoi(f) != 0; }
+  { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }   // opt-in: measured slower than the layer-wise kernels
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {

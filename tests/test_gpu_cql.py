@@ -135,15 +135,17 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
         eng.close()
 
 
-def test_cql_weight_stationary_kernels_match_tiled_kernels():
+def test_cql_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
     """Split-bf16, full size: with 4 runs per engine the 256x256 critic layers go through the weight-stationary kernels
     (csrc/ws_gemm.h: forward with fused tail + mask bits, top-layer dgrad from mask bits fused with the layer-0 weight
-    gradient); a single-run engine takes the tiled GEMM path for the same math.  Same inputs -> losses and updated
+    gradient); an engine created with ORL_WS=0 takes the tiled GEMM path for the same math.  Same inputs -> losses and updated
     critic parameters must agree to rounding (both are 3-product bf16 splits with fp32 accumulation)."""
     case = "cql_halfcheetah"
     R = 4
     eng4, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
+    monkeypatch.setenv("ORL_WS", "0")             # read at engine creation: this engine stays on the tiled kernels
     eng1, _, _, _, _ = make_engine(case, n_runs=1, precision=1)
+    monkeypatch.delenv("ORL_WS")
     try:
         for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
             m4 = eng4.step(lead(b, R), lead(noise_list(n), R))
