@@ -530,11 +530,18 @@ struct AdamP {
   float b1, b2, eps, tau;
   const unsigned long long* gstep; unsigned long long t_div;  // t = gstep / t_div + 1
 };
+// b^t for an integer step count by repeated squaring (a handful of double multiplies; the library pow() on one lane of every
+// workgroup was a measurable part of the launch)
+__device__ inline double ipow_u64(double b, unsigned long long t) {
+  double r = 1.0;
+  while (t) { if (t & 1ull) r *= b; b *= b; t >>= 1; }
+  return r;
+}
 __global__ void k_adam(AdamP p) {
   __shared__ float s_step, s_bc2s;
   if (threadIdx.x == 0) {
     const unsigned long long t = *p.gstep / p.t_div + 1ull;
-    const double bc1 = 1.0 - pow((double)p.b1, (double)t), bc2 = 1.0 - pow((double)p.b2, (double)t);
+    const double bc1 = 1.0 - ipow_u64((double)p.b1, t), bc2 = 1.0 - ipow_u64((double)p.b2, t);
     s_step = (float)((double)p.hy->lr[p.lr_slot] / bc1);
     s_bc2s = (float)sqrt(bc2);
   }
