@@ -78,6 +78,15 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       sdq[i] = dqg[m * p.dq_sm];
     }
   };
+  auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    const long m = (long)g * WS_ROWS + r;
+    s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+    sdq[i] = dqg[m * p.dq_sm];
+  };
+  auto load_mask = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+  };
   auto store_mask = [&](int buf) __attribute__((always_inline)) {
     __bf16* mi = img + (long)buf * 3 * WW_IMG;
     const int r = tid >> 4, hw = tid & 15;
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   int it = 0;
   for (int g = g0; g < p.groups; g += gs, ++it) {
     const int buf = it & 1;
-    const bool more = g + gs < p.groups;
+    const bool more = g + gs < p.groups, more2 = g + 2 * gs < p.groups;
     const __bf16* mi = img + (long)buf * 3 * WW_IMG;
     const __bf16* gh = mi + WW_IMG;
     const __bf16* gl = gh + WW_IMG;
@@ -165,13 +174,17 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
           accb[kb & 1] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, bdh, accb[kb & 1], 0, 0, 0);
         }
         // the next group's staging (VALU + LDS stores into the other buffer) is spread between the MFMAs
-        if (more) {
-          if (st == 0 && (kb & 3) == 3) store_piece(buf ^ 1, kb >> 2);
-          if (st == 1 && kb == 3) store_mask(buf ^ 1);
+        // each staging register is written to LDS and refilled at the same point of every iteration: a full iteration in flight
+        if (st == 0 && (kb & 3) == 3) {
+          if (more) store_piece(buf ^ 1, kb >> 2);
+          if (more2) load_piece(g + 2 * gs, kb >> 2);
+        }
+        if (st == 1 && kb == 3) {
+          if (more) store_mask(buf ^ 1);
+          if (more2) load_mask(g + 2 * gs);
         }
       }
     }
-    if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
     __syncthreads();
   }
 
