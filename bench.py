@@ -160,6 +160,9 @@ def main():
     ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split-bf16 MFMA (parity-gated)")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurement with ONE run per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engines-per-gpu", type=int, default=int(os.environ.get("ORL_ENGINES_PER_GPU", "2")),
+                    help="independent engines per GPU (each --runs-per-gpu runs, own HIP stream and host thread): the launch-latency-bound "
+                         "256-row phases of one engine overlap the many-row launches of the other")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--profile-dump", default="", help="write the full per-launch-tag timing table (HIP events) to this file")
     ap.add_argument("--dataset-size", type=int, default=1_000_000)
@@ -189,13 +192,38 @@ def main():
     cfg = _engine.default_config("cql", obs_dim=OBS, act_dim=ACT, hidden=HIDDEN, batch_size=BATCH, n_runs=R,
                                  device=local_rank, precision=args.precision, seed=1234 + 7919 * rank,
                                  num_repeat_actions=NREP, target_entropy=-float(ACT))
-    eng = _engine.Engine(cfg)
+    E = max(1, args.engines_per_gpu)
     ds = make_dataset(rank, args.dataset_size)
     buf = _engine.DeviceBuffer(OBS, ACT, local_rank)
     buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
-    eng.attach_buffer(buf)
-    for r in range(R):
-        init_weights(eng, r, rank * R + r)
+    engines = []
+    for e in range(E):
+        cfg_e = _engine.default_config("cql", obs_dim=OBS, act_dim=ACT, hidden=HIDDEN, batch_size=BATCH, n_runs=R,
+                                       device=local_rank, precision=args.precision, seed=1234 + 7919 * (rank * E + e),
+                                       num_repeat_actions=NREP, target_entropy=-float(ACT))
+        g = _engine.Engine(cfg_e) if e else _engine.Engine(cfg)
+        g.attach_buffer(buf)                             # all engines of a GPU sample the same HBM-resident dataset
+        for r in range(R):
+            init_weights(g, r, (rank * E + e) * R + r)
+        engines.append(g)
+    eng = engines[0]
+
+    import threading
+
+    def learn_all(n):
+        """every engine advances n gradient steps (all its runs); one host thread per engine, each on its own HIP stream"""
+        res = [None] * E
+        def work(i):
+            res[i] = engines[i].learn_n(n)
+        if E == 1:
+            work(0)
+        else:
+            ths = [threading.Thread(target=work, args=(i,)) for i in range(E)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        return res
 
     def barrier():
         torch.cuda.synchronize()
@@ -204,12 +232,14 @@ def main():
         torch.cuda.synchronize()
 
     if args.warmup > 0:
-        eng.learn_n(args.warmup)
+        learn_all(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    metrics, ev_ms = eng.learn_n(args.steps)          # synchronises the engine stream before returning
+    res = learn_all(args.steps)                       # every engine synchronises its stream before returning
     barrier()
     dt = time.perf_counter() - t0
+    metrics, ev_ms = res[0]
+    metrics = np.concatenate([m for m, _ in res], axis=0)       # (E * R, n_metrics)
     if dist is not None:
         t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,7 +253,7 @@ def main():
         metrics_all = metrics[None]
     assert np.isfinite(metrics_all).all(), "non-finite losses"
 
-    total_steps = args.steps * R * world
+    total_steps = args.steps * R * E * world
     value = total_steps / dt
     out = None
     single = None
@@ -283,8 +313,8 @@ def main():
             "dtype": DTYPE[args.precision],
             "data": "synthetic D4RL-shaped replay buffer (N(0,1) obs, tanh actions), random-init weights",
             "config": {"workload": "CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
-                                   "auto-alpha, device sampling+noise, %d run(s)/GPU x %d GPU(s) (independent seeds)" % (R, world),
-                       "runs_per_gpu": R, "dataset_transitions": args.dataset_size, "event_ms_per_step": ev_ms / args.steps,
+                                   "auto-alpha, device sampling+noise, %d engine(s) x %d run(s) per GPU x %d GPU(s) (independent seeds)" % (E, R, world),
+                       "runs_per_gpu": R * E, "engines_per_gpu": E, "runs_per_engine": R, "dataset_transitions": args.dataset_size, "event_ms_per_step": ev_ms / args.steps,
                        "algorithmic_gflop_per_gradient_step": flops_step / 1e9},
             "roofline": roof, "cpu_baseline": cpu, "single_run": single,
             "final_metrics_rank0_run0": dict(zip(eng.metric_names, [float(x) for x in metrics[0]])),
