@@ -163,7 +163,7 @@ struct Engine {
   int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag,
                    const Mat* w0_X = nullptr, bool store_dx = true, int* w0_slabs = nullptr);
   int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                   const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr);
+                   const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr, int* slabs_out = nullptr);
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
   int polyak(int target_net, int src_net, int nnets);
   void prof_begin(const char* name, double flops, double bytes = 0);

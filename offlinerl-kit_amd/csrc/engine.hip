@@ -500,8 +500,9 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
   return ks;
 }
 
+// slabs_out: number of split-K slabs actually written (== ksplit unless the weight-stationary kernel chose its own decomposition)
 int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                         const char* tag, int in_row0, int in_rows, bool* fuse_tail) {
+                         const char* tag, int in_row0, int in_rows, bool* fuse_tail, int* slabs_out) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
@@ -529,6 +530,32 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   p.c_s0 = g_rs; p.c_s1 = l.w_ms[layer]; p.c_ks = P_train;
   if (with_bias) { p.bias_out = g + l.b_off[layer]; p.bo_s0 = g_rs; p.bo_s1 = l.b_ms[layer]; p.bo_ks = P_train; }
   const int nz = R * nr.nz1;
+  if (slabs_out) *slabs_out = ksplit;
+  // output-stationary kernel (csrc/ws_gemm.h): dz^T from the packed ReLU mask, G = dq (.) X streamed once; the tail layer's own
+  // gradients then come from their separate small launch (caller, *fuse_tail = false)
+  if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens &&
+      dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && in_row0 == 0 && in_rows == in && X.pitch == in &&
+      (long)M * nz >= 40000) {
+    WsWgradP w;
+    memset(&w, 0, sizeof(w));
+    w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
+    w.dq = dy.rowv.p; w.dq_s0 = dy.rowv.rs; w.dq_s1 = dy.rowv.cs; w.dq_sm = dy.rowv.pitch;
+    w.H0 = X.p; w.h0_s0 = X.rs; w.h0_s1 = X.cs; w.h0_pitch = X.pitch;
+    w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
+    w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
+    w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
+    w.M = M; w.nz1 = nr.nz1;
+    if (ws_wgrad_supported(w, out, in)) {
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab);
+      prof_begin(tag, 2.0 * M * (double)in * (out + 1) * nz, nz * (M * (double)out / 8 + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 1)));
+      hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
+      *fuse_tail = false;
+      *slabs_out = per_z;
+      return 0;
+    }
+  }
   if (fuse_tail) {
     // the rank-1 kernel streams h and dq anyway: let it also emit the tail layer's dw / db (same split-K slabs)
     *fuse_tail = dy.rank1 && rank1_wgrad_is_fast(p, force_scalar);
@@ -653,7 +680,9 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
     if (want_w && !(i == 0 && w0_done)) {
       bool fused = false;
       const bool top = rank1 && (i == L - 1);
-      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr)) return -1;
+      int slabs = ks[i];
+      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr, &slabs)) return -1;
+      ks[i] = slabs;
       if (top) {
         if (fused) ks[L] = ks[i];           // the tail gradients were written into the same split-K slabs
         else if (e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
