@@ -531,8 +531,8 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   if (with_bias) { p.bias_out = g + l.b_off[layer]; p.bo_s0 = g_rs; p.bo_s1 = l.b_ms[layer]; p.bo_ks = P_train; }
   const int nz = R * nr.nz1;
   if (slabs_out) *slabs_out = ksplit;
-  // output-stationary kernel (csrc/ws_gemm.h): dz^T from the packed ReLU mask, G = dq (.) X streamed once; the tail layer's own
-  // gradients then come from their separate small launch (caller, *fuse_tail = false)
+  // output-stationary kernel (csrc/ws_gemm.h): dz^T from the packed ReLU mask, G = dq (.) X and the activation itself streamed once;
+  // the tail layer's gradients ride along (*fuse_tail = true, same slabs)
   if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && in_row0 == 0 && in_rows == in && X.pitch == in &&
       (long)M * nz >= 40000) {
@@ -544,14 +544,17 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
     w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
+    // the activation values are streamed through registers as well: tail-layer gradients (and db) from the same pass, same slabs
+    w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch;
+    w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
     w.M = M; w.nz1 = nr.nz1;
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab);
-      prof_begin(tag, 2.0 * M * (double)in * (out + 1) * nz, nz * (M * (double)out / 8 + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 1)));
+      prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz, nz * (4.0 * M * (double)out + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
-      *fuse_tail = false;
+      *fuse_tail = true;
       *slabs_out = per_z;
       return 0;
     }

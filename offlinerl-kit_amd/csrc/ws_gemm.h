@@ -605,10 +605,11 @@ static inline hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipSt
 }
 
 // =====================================================================================================================
-// ws_wgrad: weight gradient of the top hidden layer of a single-output net, output-stationary.
+// ws_wgrad: weight gradient of the top hidden layer of a single-output net, output-stationary (+ the tail layer's gradients).
 //
 //   dW1[k][n] = w_tail[k] * sum_m 1[h1[m][k] > 0] * (dq[m] * h0[m][n])        db1[k] = w_tail[k] * sum_m 1[h1[m][k] > 0] * dq[m]
-// (the tail layer's own gradients need the VALUES of h1 and come from a separate small launch)
+//   TAILS variant: dw_tail[k] = sum_m dq[m] h1[m][k], db_tail = sum_m dq[m] and db1 from h1 streamed through registers (VALU), in
+//   the shadow of the MFMAs -- no separate HBM-bound launch for them
 //
 // The 256 x 256 result stays in registers for the whole launch: wave w owns columns n in [32w, 32w+32) and all 256 rows k
 // (16 x 2 blocks of 16 x 16 = 128 accumulator VGPRs) and the workgroup streams 32-row groups of the batch.  Both MFMA
@@ -626,6 +627,10 @@ struct WsWgradP {
   const float* wt; long wt_s0, wt_s1;                          // w_tail [256]
   float *dW, *db;                                              // slab outputs; run stride o_s0, member strides below, slab stride o_ks
   long o_s0, o_s1w, o_s1b, o_ks;
+  // TAILS variant: h1 itself is streamed too (through registers only) and the launch also produces the tail layer's gradients
+  //   dw_tail[k] = sum_m dq[m] h1[m][k],  db_tail = sum_m dq[m];  db1 then comes from the same pass (no MFMA operand for it)
+  const float* H1; long h1_s0, h1_s1; int h1_pitch;
+  float *dwt, *dbt; long o_s1wt, o_s1bt;
   int M, nz1, groups;
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
@@ -643,6 +648,7 @@ __device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
 }
 
+template <bool TAILS>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
@@ -664,6 +670,10 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 
   // ---- staging registers of one row group ----
   f32x4 s0[4];
+  f32x4 s1[TAILS ? 4 : 1];
+  f32x4 tacc = (f32x4){0.f, 0.f, 0.f, 0.f}, bacc = (f32x4){0.f, 0.f, 0.f, 0.f};   // TAILS: dw_tail / db1 partials of columns 4 (tid & 63) ..
+  float dqsum = 0.f;
+  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
   float sdq[4];
   unsigned int sm_word;
   __bf16* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
@@ -674,6 +684,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
       const long m = (long)g * WS_ROWS + r;
       s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+      if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
       sdq[i] = dqg[m * p.dq_sm];
     }
   };
@@ -681,6 +692,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
     const long m = (long)g * WS_ROWS + r;
     s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+    if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
     sdq[i] = dqg[m * p.dq_sm];
   };
   auto load_mask = [&](int g) __attribute__((always_inline)) {
@@ -713,7 +725,11 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     const int o = ww_off(r, kq >> 1, kq & 1);
     *(bf16x4*)(gh + o) = h;
     *(bf16x4*)(gl + o) = l;
-    if (kq == 0) {                                                   // this row's dq into the bias-gradient operand block
+    if (TAILS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { tacc[j] += sdq[i] * s1[i][j]; bacc[j] += s1[i][j] > 0.f ? sdq[i] : 0.f; }
+      dqsum += sdq[i];
+    } else if (kq == 0) {                                            // this row's dq into the bias-gradient operand block
       const __bf16 hh = (__bf16)sdq[i];
       __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
       dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = (__bf16)(sdq[i] - (float)hh);
@@ -724,7 +740,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
-  for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
+  if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
   __syncthreads();
 
   const int g0 = blockIdx.x, gs = gridDim.x;
@@ -758,9 +774,12 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       }
       const int dro0 = (4 * lq + (li >> 2)) * 16 + 4 * (li & 3), dro1 = dro0 + 16 * 16;
       typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-      const bf16x8 bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
-      const bf16x8 bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
-                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
+      bf16x8 bdh, bdl;
+      if (!TAILS) {
+        bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
+        bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
+                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
+      }
 #pragma unroll
       for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
         const int kb0 = 2 * kp, kb1 = kb0 + 1;
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
         for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[nb], acc[kb0][nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[nb], acc[kb1][nb], 0, 0, 0);
-        if (kp == wave) {                                            // uniform per wave: this wave's share of db1
+        if (!TAILS && kp == wave) {                                  // uniform per wave: this wave's share of db1
           accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bdl, accb[0], 0, 0, 0);
           accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bdl, accb[1], 0, 0, 0);
           accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bdh, accb[0], 0, 0, 0);
@@ -806,30 +825,55 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
   }
-  if (li == 0) {
+  if (!TAILS) {
+    if (li == 0) {
 #pragma unroll
-    for (int x = 0; x < 2; ++x) {
-      const int k0 = 16 * (2 * wave + x) + 4 * lq;
+      for (int x = 0; x < 2; ++x) {
+        const int k0 = 16 * (2 * wave + x) + 4 * lq;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
+        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
+      }
     }
+    return;
+  }
+  // TAILS: eight row-slice partial sums per column (threads tid, tid + 64, ...), summed in a fixed order
+  float* red = ws_smem;                                              // the images are dead after the loop's last barrier
+  *(f32x4*)&red[(tid >> 6) * WS_K + 4 * (tid & 63)] = tacc;
+  *(f32x4*)&red[(8 + (tid >> 6)) * WS_K + 4 * (tid & 63)] = bacc;
+  if ((tid & 63) == 0) red[16 * WS_K + (tid >> 6)] = dqsum;
+  __syncthreads();
+  if (tid < WS_K) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += red[w * WS_K + tid]; b += red[(8 + w) * WS_K + tid]; }
+    p.dwt[so + z1 * p.o_s1wt + tid] = a;
+    db[tid] = wtg[tid] * b;
+  }
+  if (tid == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[16 * WS_K + w];
+    p.dbt[so + z1 * p.o_s1bt] = a;
   }
 }
 
 static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.abits || p.ab_g != 8) return false;
   if (!aligned16(p.H0) || (p.h0_pitch & 3) || (p.h0_s0 & 3) || (p.h0_s1 & 3)) return false;
+  if (p.H1 && (!aligned16(p.H1) || (p.h1_pitch & 3) || (p.h1_s0 & 3) || (p.h1_s1 & 3) || !p.dwt || !p.dbt)) return false;
   return aligned16(p.wt) && !(p.wt_s0 & 3) && !(p.wt_s1 & 3);
 }
 static inline hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
   static bool raised = false;
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
     if (e != hipSuccess) return e;
     raised = true;
   }
-  hipLaunchKernelGGL(ws_wgrad_kernel, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
   return hipGetLastError();
 }
 

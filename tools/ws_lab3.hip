@@ -28,6 +28,8 @@ int main(int argc, char** argv) {
   WsWgradP p; memset(&p, 0, sizeof(p));
   p.abits = dab; p.ab_s1 = (long)M * 8; p.ab_g = 8; p.dq = ddq; p.dq_s1 = M; p.dq_sm = 1;
   p.H0 = d0; p.h0_s1 = nH; p.h0_pitch = 256; p.wt = dwt; p.wt_s1 = 256;
+  const bool tails = argc > 3 && atoi(argv[3]) == 1;
+  if (tails) { p.H1 = d1; p.h1_s1 = nH; p.h1_pitch = 256; p.dwt = dG + 65536 + 256; p.dbt = dG + 65536 + 512; p.o_s1wt = p.o_s1bt = (long)SL * P; }
   p.dW = dG; p.db = dG + 65536;
   p.o_s1w = p.o_s1b = (long)SL * P; p.o_ks = P; p.M = M; p.nz1 = nz;
   if (!ws_wgrad_supported(p, 256, 256)) { printf("not supported\n"); return 1; }
@@ -53,7 +55,7 @@ int main(int argc, char** argv) {
         e[w] = std::max(e[w], std::fabs(got - ref[i])); sc[w] = std::max(sc[w], std::fabs(ref[i]));
       }
     }
-    printf("M=%d nz=%d blocks/z=%d  rel err: dW1 %.2e  db1 %.2e\n", M, nz, per_z, e[0] / sc[0], e[1] / sc[1]);
+    printf("M=%d nz=%d blocks/z=%d  rel err: dW1 %.2e  db1 %.2e  dw_tail %.2e  db_tail %.2e\n", M, nz, per_z, e[0] / sc[0], e[1] / sc[1], e[2] / sc[2], e[3] / sc[3]);
   }
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) CK(launch_ws_wgrad(p, nz, per_z, 0));
