@@ -585,7 +585,7 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
   a.b1 = cfg.adam_beta1; a.b2 = cfg.adam_beta2; a.eps = cfg.adam_eps; a.tau = cfg.tau;
   a.gstep = gstep; a.t_div = t_div;
-  ORL_LAUNCH("adam", k_adam, dim3((unsigned)((l.size + 255) / 256), nnets, R), dim3(256), a);
+  ORL_LAUNCH("adam", k_adam, dim3((unsigned)((l.size + 1023) / 1024), nnets, R), dim3(256), a);    // four parameters per thread
   return 0;
 }
 

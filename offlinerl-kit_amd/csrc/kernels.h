@@ -537,6 +537,20 @@ __device__ inline double ipow_u64(double b, unsigned long long t) {
   while (t) { if (t & 1ull) r *= b; b *= b; t >>= 1; }
   return r;
 }
+// One thread updates four consecutive parameters (16-byte loads / stores of p, m, v, the slabs and the target) when they belong to
+// one tensor group; the few groups that straddle a boundary (a scalar bias at the end of a net) fall back to single elements.
+__device__ inline float adam_slab_sum(const float* g, long ks, int nslab) {
+  if (nslab == 1) return g[0];
+  float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};            // fixed order, eight independent partial sums
+  int s = 0;
+  for (; s + 8 <= nslab; s += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] += g[(long)(s + j) * ks];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (s + j < nslab) q[j] += g[(long)(s + j) * ks];
+  return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+}
 __global__ void k_adam(AdamP p) {
   __shared__ float s_step, s_bc2s;
   if (threadIdx.x == 0) {
@@ -546,35 +560,58 @@ __global__ void k_adam(AdamP p) {
     s_bc2s = (float)sqrt(bc2);
   }
   __syncthreads();
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= p.P) return;
+  const long i0 = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (i0 >= p.P) return;
   const int z1 = blockIdx.y, z0 = blockIdx.z;
-  const float* g = p.g + z0 * p.g_s0 + z1 * p.g_s1 + i;
-  int nslab = p.seg_nslab[0];
-  for (int k = 1; k < p.nseg; ++k) if (i >= p.seg_end[k - 1]) nslab = p.seg_nslab[k];
-  // split-K slabs summed in a fixed order with eight independent partial sums (many slabs: the loads stay in flight)
-  float gs;
-  if (nslab == 1) gs = g[0];
-  else {
-    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 8 <= nslab; s += 8) {
+  const float* g = p.g + z0 * p.g_s0 + z1 * p.g_s1;
+  const long o = z0 * p.p_s0 + z1 * p.p_s1;
+  float* tg = p.target ? p.target + z0 * p.t_s0 + z1 * p.t_s1 : nullptr;
+  int sg = 0;
+  while (sg < p.nseg - 1 && i0 >= p.seg_end[sg]) ++sg;
+  const bool vec = (i0 + 4 <= p.P) && (i0 + 3 < p.seg_end[sg] || sg == p.nseg - 1) && ((o & 3) == 0) && ((p.g_ks & 3) == 0) &&
+                   (((p.g_s0 | p.g_s1) & 3) == 0) && (!tg || (((p.t_s0 | p.t_s1) & 3) == 0));
+  if (vec) {
+    const int nslab = p.seg_nslab[sg];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 gs;
+    if (nslab == 1) gs = *(const f4*)&g[i0];
+    else {
+      f4 q[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // fixed order, four partial sums
+      int s = 0;
+      for (; s + 4 <= nslab; s += 4) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) q[j] += g[(long)(s + j) * p.g_ks];
+        for (int j = 0; j < 4; ++j) q[j] += *(const f4*)&g[i0 + (long)(s + j) * p.g_ks];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (s + j < nslab) q[j] += *(const f4*)&g[i0 + (long)(s + j) * p.g_ks];
+      gs = (q[0] + q[1]) + (q[2] + q[3]);
     }
+    f4 m = *(const f4*)&p.m[o + i0], v = *(const f4*)&p.v[o + i0], w = *(const f4*)&p.params[o + i0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) if (s + j < nslab) q[j] += g[(long)(s + j) * p.g_ks];
-    gs = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    for (int j = 0; j < 4; ++j) {
+      m[j] = m[j] + (gs[j] - m[j]) * (1.0f - p.b1);
+      v[j] = v[j] * p.b2 + (1.0f - p.b2) * gs[j] * gs[j];
+      w[j] -= s_step * (m[j] / (sqrtf(v[j]) / s_bc2s + p.eps));
+    }
+    *(f4*)&p.m[o + i0] = m; *(f4*)&p.v[o + i0] = v; *(f4*)&p.params[o + i0] = w;
+    if (tg) {
+      f4 t = *(const f4*)&tg[i0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t[j] = t[j] * (1.0f - p.tau) + w[j] * p.tau;
+      *(f4*)&tg[i0] = t;
+    }
+    return;
   }
-  const long o = z0 * p.p_s0 + z1 * p.p_s1 + i;
-  float m = p.m[o], v = p.v[o], w = p.params[o];
-  m = m + (gs - m) * (1.0f - p.b1);
-  v = v * p.b2 + (1.0f - p.b2) * gs * gs;
-  w -= s_step * (m / (sqrtf(v) / s_bc2s + p.eps));
-  p.m[o] = m; p.v[o] = v; p.params[o] = w;
-  if (p.target) {
-    float* t = p.target + z0 * p.t_s0 + z1 * p.t_s1 + i;
-    *t = *t * (1.0f - p.tau) + w * p.tau;
+  for (long i = i0; i < i0 + 4 && i < p.P; ++i) {
+    int nslab = p.seg_nslab[0];
+    for (int k = 1; k < p.nseg; ++k) if (i >= p.seg_end[k - 1]) nslab = p.seg_nslab[k];
+    const float gs = adam_slab_sum(g + i, p.g_ks, nslab);
+    float m = p.m[o + i], v = p.v[o + i], w = p.params[o + i];
+    m = m + (gs - m) * (1.0f - p.b1);
+    v = v * p.b2 + (1.0f - p.b2) * gs * gs;
+    w -= s_step * (m / (sqrtf(v) / s_bc2s + p.eps));
+    p.m[o + i] = m; p.v[o + i] = v; p.params[o + i] = w;
+    if (tg) tg[i] = tg[i] * (1.0f - p.tau) + w * p.tau;
   }
 }
 
