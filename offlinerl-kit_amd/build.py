@@ -12,11 +12,23 @@ HEADERS = ["engine.h", "gemm.h", "kernels.h", "ws_gemm.h", "mlp_fused.h", "algo_
            os.path.join("..", "..", "include", "orl_engine.h")]
 
 
+STAMP = LIB + ".srchash"      # content hash of the sources the library was built from (file times do not survive every copy)
+
+
+def source_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    with open(STAMP) as fh:
+        return fh.read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
@@ -27,7 +39,10 @@ def build(force=False, verbose=True):
            "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
+    h = source_hash()                      # hash what is about to be compiled
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as fh:
+        fh.write(h + "\n")
     return LIB
 
 
