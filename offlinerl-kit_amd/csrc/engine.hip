@@ -285,12 +285,13 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
-  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens && !use_fused && in_row0 == 0 && in_rows == in &&
+  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && !use_fused && in_row0 == 0 && in_rows == in &&
       Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
     w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch;
     w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    if (l.ens) { w.w_sn = 1; w.w_sk = out; } else { w.w_sn = in; w.w_sk = 1; }      // EnsembleLinear keeps (in, out)-major weights
     w.bias = nr.base + l.b_off[layer]; w.b_s0 = nr.rs; w.b_s1 = l.b_ms[layer];
     w.Y = Y.p; w.y_s0 = Y.rs; w.y_s1 = Y.cs; w.y_pitch = Y.pitch;
     w.mb = Y.bits; w.mb_s0 = Y.brs; w.mb_s1 = Y.bcs; w.mb_g = Y.bg;
@@ -306,6 +307,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     if (ws_ok && fuse_X0 && layer == 1 && X.bits && X.pitch == in) {
       w.X0 = fuse_X0->p; w.x0_s0 = fuse_X0->rs; w.x0_s1 = fuse_X0->cs; w.x0_pitch = fuse_X0->pitch; w.in0 = l.layer_in(0);
       w.W0 = nr.base + l.w_off[0]; w.w0_s0 = nr.rs; w.w0_s1 = l.w_ms[0];
+      if (l.ens) { w.w0_sn = 1; w.w0_sk = l.layer_out(0); } else { w.w0_sn = l.layer_in(0); w.w0_sk = 1; }
       w.b0 = nr.base + l.b_off[0]; w.b0_s0 = nr.rs; w.b0_s1 = l.b_ms[0];
       w.mb0 = X.bits; w.mb0_s0 = X.brs; w.mb0_s1 = X.bcs; w.mb0_g = X.bg;
       fused0 = ws_fwd01_supported(w) && aligned16(fuse_X0->p);

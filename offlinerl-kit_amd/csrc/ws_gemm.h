@@ -28,7 +28,8 @@ namespace orl {
 
 struct WsFwdP {
   const float* X; long x_s0, x_s1; int x_pitch;        // input activations [z][M][K] fp32, K == 256
-  const float* W; long w_s0, w_s1;                      // weights (out, in) row-major [z][256][256]
+  const float* W; long w_s0, w_s1;                      // weights of problem z; element (n, k) at W[n * w_sn + k * w_sk]:
+  long w_sn, w_sk;                                      //   nn.Linear (out, in): w_sn = 256, w_sk = 1; EnsembleLinear (in, out): w_sn = 1, w_sk = 256
   const float* bias; long b_s0, b_s1;
   float* Y; long y_s0, y_s1; int y_pitch;               // relu(X W^T + b) [z][M][256]
   unsigned int* mb; long mb_s0, mb_s1; int mb_g;        // packed ReLU mask of Y (gemm.h layout) or null
@@ -39,7 +40,7 @@ struct WsFwdP {
   // fused first layer (template L0): X is then PRODUCED here as relu(X0 W0^T + b0) from the narrow input rows X0 (in0 + 1 <= 32 columns
   // incl. the bias as a ones column), stored to `X` for the backward pass, and handed to the second layer through LDS only
   const float* X0; long x0_s0, x0_s1; int x0_pitch, in0;
-  const float* W0; long w0_s0, w0_s1;                   // (256, in0) row-major
+  const float* W0; long w0_s0, w0_s1, w0_sn, w0_sk;     // element (n, k) at W0[n * w0_sn + k * w0_sk] ((256, in0) row-major: in0, 1)
   const float* b0; long b0_s0, b0_s1;
   unsigned int* mb0; long mb0_s0, mb0_s1; int mb0_g;    // packed ReLU mask of X (= h0)
 };
@@ -87,8 +88,14 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   for (int cb = 0; cb < WS_CB; ++cb)
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const float* src = Wg + (long)(ncol0 + 16 * cb + li) * WS_K + 32 * ks + 8 * lq;
-      ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
+      const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
+      if (p.w_sk == 1) ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
+      else {                                           // (in, out)-major weights: eight strided loads, once per workgroup
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = src[(long)j * p.w_sk]; b[j] = src[(long)(4 + j) * p.w_sk]; }
+        ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
+      }
     }
   // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
   bf16x8 b0h[WS_CB], b0l[WS_CB];
@@ -102,8 +109,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k0 = 8 * lq + j, k1 = k0 + 4;
-        a[j] = k0 < p.in0 ? W0g[(long)n * p.in0 + k0] : (k0 == p.in0 ? b0g[n] : 0.f);
-        b[j] = k1 < p.in0 ? W0g[(long)n * p.in0 + k1] : (k1 == p.in0 ? b0g[n] : 0.f);
+        a[j] = k0 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k0 * p.w0_sk] : (k0 == p.in0 ? b0g[n] : 0.f);
+        b[j] = k1 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k1 * p.w0_sk] : (k1 == p.in0 ? b0g[n] : 0.f);
       }
       ws_split8(a, b, b0h[cb], b0l[cb]);
     }
@@ -340,7 +347,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.mb) return false;
   if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
-  if (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || !aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
+  if (p.w_sk == 1 && (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || (p.w_sn & 3))) return false;
+  if (!aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
   if (!aligned16(p.Y) || (p.y_pitch & 3) || (p.y_s0 & 3) || (p.y_s1 & 3)) return false;
   if (p.tq && (!aligned16(p.tw) || (p.tw_s0 & 3) || (p.tw_s1 & 3))) return false;
   return true;

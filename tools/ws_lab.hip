@@ -38,14 +38,14 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(db, hb.data(), 4 * 256 * nz, hipMemcpyHostToDevice)); CK(hipMemcpy(dtw, htw.data(), 4 * 256 * nz, hipMemcpyHostToDevice));
   CK(hipMemcpy(dtb, htb.data(), 4 * nz, hipMemcpyHostToDevice)); CK(hipMemset(dmb, 0, 4L * M * 8 * nz));
   WsFwdP p; memset(&p, 0, sizeof(p));
-  p.X = dX; p.x_s1 = nX; p.x_pitch = 256; p.W = dW; p.w_s1 = nW; p.bias = db; p.b_s1 = 256; p.Y = dY; p.y_s1 = nX; p.y_pitch = 256;
+  p.X = dX; p.x_s1 = nX; p.x_pitch = 256; p.W = dW; p.w_s1 = nW; p.w_sn = 256; p.w_sk = 1; p.bias = db; p.b_s1 = 256; p.Y = dY; p.y_s1 = nX; p.y_pitch = 256;
   p.mb = dmb; p.mb_s1 = (long)M * 8; p.mb_g = 8; p.tw = dtw; p.tw_s1 = 256; p.tb = dtb; p.tb_s1 = 1; p.tq = dq; p.tq_s1 = M; p.tq_sm = 1;
   p.M = M; p.nz1 = nz;
   float *dX0, *dW0, *db0; unsigned* dmb0;
   CK(hipMalloc(&dX0, 4L * M * xp * nz)); CK(hipMalloc(&dW0, 4 * 256L * in0 * nz)); CK(hipMalloc(&db0, 4 * 256 * nz)); CK(hipMalloc(&dmb0, 4L * M * 8 * nz));
   CK(hipMemcpy(dX0, hX0.data(), 4L * M * xp * nz, hipMemcpyHostToDevice)); CK(hipMemcpy(dW0, hW0.data(), 4 * 256L * in0 * nz, hipMemcpyHostToDevice));
   CK(hipMemcpy(db0, hb0.data(), 4 * 256 * nz, hipMemcpyHostToDevice));
-  if (l0) { CK(hipMemset(dX, 0, 4 * nX * nz)); p.X0 = dX0; p.x0_s1 = (long)M * xp; p.x0_pitch = xp; p.in0 = in0; p.W0 = dW0; p.w0_s1 = 256L * in0; p.b0 = db0; p.b0_s1 = 256;
+  if (l0) { CK(hipMemset(dX, 0, 4 * nX * nz)); p.X0 = dX0; p.x0_s1 = (long)M * xp; p.x0_pitch = xp; p.in0 = in0; p.W0 = dW0; p.w0_s1 = 256L * in0; p.w0_sn = in0; p.w0_sk = 1; p.b0 = db0; p.b0_s1 = 256;
             p.mb0 = dmb0; p.mb0_s1 = (long)M * 8; p.mb0_g = 8; if (!ws_fwd01_supported(p)) { printf("l0 not supported\n"); return 1; } }
   if (!ws_fwd_supported(p, 256, 256)) { printf("not supported\n"); return 1; }
   CK(launch_ws_fwd(p, nz, 0)); CK(hipDeviceSynchronize());
