@@ -458,6 +458,27 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
       *w0_slabs = slabs;
     }
   }
+  // plain (materialised) dz through a 256 x 256 layer with the ReLU mask of the receiving activation: the weight-stationary kernel
+  // in gradient mode (B = the weights viewed transposed, epilogue = mask from bits)
+  if (!dy.rank1 && !p.w0_out && maskH && p.aux_bits && col0 == 0 && ncols == in && this->cfg.precision == 1 && use_ws && !force_scalar &&
+      dy.m.pitch == out && dX.pitch == in && (long)M * nz >= 4096) {
+    WsFwdP w;
+    memset(&w, 0, sizeof(w));
+    w.X = dy.m.p; w.x_s0 = dy.m.rs; w.x_s1 = dy.m.cs; w.x_pitch = dy.m.pitch;
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    // B[n = input unit][k = output unit]: nn.Linear W (out, in) -> element (k, n) at k * in + n; EnsembleLinear (in, out) -> n * out + k
+    if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
+    w.Y = dX.p; w.y_s0 = dX.rs; w.y_s1 = dX.cs; w.y_pitch = dX.pitch;
+    w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
+    w.M = M; w.nz1 = nr.nz1;
+    if (ws_fwd_supported(w, out, in)) {
+      prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
+      hipError_t err = launch_ws_fwd(w, nz, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws dgrad launch ") + tag + ": " + hipGetErrorString(err));
+      return 0;
+    }
+  }
   if (dy.rank1) {
     if (maskH && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch) {
       // the virtual dz of the top hidden layer from its packed ReLU mask: the activation matrix is not read at all

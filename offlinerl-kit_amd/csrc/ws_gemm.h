@@ -43,6 +43,9 @@ struct WsFwdP {
   const float* W0; long w0_s0, w0_s1, w0_sn, w0_sk;     // element (n, k) at W0[n * w0_sn + k * w0_sk] ((256, in0) row-major: in0, 1)
   const float* b0; long b0_s0, b0_s1;
   unsigned int* mb0; long mb0_s0, mb0_s1; int mb0_g;    // packed ReLU mask of X (= h0)
+  // plain dgrad mode (template DG): Y = (X B^T) (.) mask, B given by the strides above (W viewed transposed), no bias / ReLU / mask
+  // emission; `dmask` = packed ReLU mask of the activation the gradient flows into
+  const unsigned int* dmask; long dm_s0, dm_s1; int dm_g;
 };
 
 #ifndef WS_WAVES
@@ -64,7 +67,7 @@ __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16
   }
 }
 
-template <bool TQ, bool L0>
+template <bool TQ, bool L0, bool DG = false>
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
-  const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
+  const float* __restrict__ bg = DG ? nullptr : p.bias + z0 * p.b_s0 + z1 * p.b_s1;
   float* __restrict__ Yg = p.Y + z0 * p.y_s0 + z1 * p.y_s1;
   const int ncol0 = 16 * WS_CB * wave;
   float* __restrict__ Y0g = L0 ? const_cast<float*>(Xg) : nullptr;       // L0: h0 is written where the plain kernel reads it
@@ -233,6 +236,24 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const float* __restrict__ twg2 = twg;
   auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
     float* qsw = qs + (par * WS_NW + wave) * WS_ROWS;
+    if (DG) {                                      // gradient epilogue: ReLU mask of the receiving activation from its packed bits
+      static_assert(!DG || WS_CB == 2, "one 32-column mask word per wave");
+      const unsigned int* __restrict__ dm = p.dmask + z0 * p.dm_s0 + z1 * p.dm_s1;
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const long m = (long)g * WS_ROWS + 16 * s + li;
+        const unsigned int w = dm[m * p.dm_g + wave];
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) {
+          const unsigned int nib = w >> (16 * cb + 4 * lq);
+          f32x4 v = acc[s][cb];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] : 0.f;
+          *(f32x4*)&Yg[m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+        }
+      }
+      return;
+    }
     f32x4 bq[WS_CB], twq[WS_CB];
 #pragma unroll
     for (int cb = 0; cb < WS_CB; ++cb) {
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     }
   };
   auto finish = [&](int g, int par) __attribute__((always_inline)) {   // after the barrier that follows epilogue(g)
+    if (DG) return;
     if (tid < WS_ROWS * 8) {                         // thread (row, word): eight nibbles -> one 32-column mask word
       const int row = tid >> 3, wd = tid & 7, m = g * WS_ROWS + row;
       const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * 64 + 8 * wd);
@@ -345,10 +367,11 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
 // host: does the launch qualify?  (split-bf16 precision, K = N = 256, 16-byte aligned operands)
 static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
-  if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.mb) return false;
+  if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || (!p.mb && !p.dmask)) return false;
   if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
   if (p.w_sk == 1 && (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || (p.w_sn & 3))) return false;
-  if (!aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
+  if (p.dmask) { if (p.tq || p.X0 || p.dm_g != 8) return false; }
+  else if (!aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
   if (!aligned16(p.Y) || (p.y_pitch & 3) || (p.y_s0 & 3) || (p.y_s1 & 3)) return false;
   if (p.tq && (!aligned16(p.tw) || (p.tw_s0 & 3) || (p.tw_s1 & 3))) return false;
   return true;
@@ -375,11 +398,13 @@ static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e != hipSuccess) return e;
     raised = true;
   }
   const dim3 grid(per_z, 1, nz), block(WS_NT);
-  if (l0) {
+  if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true>), grid, block, lds, st, p);
+  else if (l0) {
     if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((ws_fwd_kernel<false, true>), grid, block, lds, st, p);
   } else {
