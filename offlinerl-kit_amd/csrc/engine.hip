@@ -408,7 +408,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.xbits = maskH->bits; w.xb_s0 = maskH->brs; w.xb_s1 = maskH->bcs; w.xb_g = maskH->bg;
     w.dq = dy.rowv.p; w.dq_s0 = dy.rowv.rs; w.dq_s1 = dy.rowv.cs; w.dq_sm = dy.rowv.pitch;
     w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
-    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer]; w.w_sn = 1; w.w_sk = in;
     w.X = w0_X->p; w.x_s0 = w0_X->rs; w.x_s1 = w0_X->cs; w.x_pitch = w0_X->pitch; w.in0 = l.layer_in(0);
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
@@ -426,7 +426,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     }
   }
   // same kernel, storing variant (no layer-0 gradient): e.g. the critic backward of the actor loss, where dz0 feeds dL/da
-  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !l.ens && !force_scalar && this->cfg.precision == 1 && use_ws && p.aux_bits &&
+  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !force_scalar && this->cfg.precision == 1 && use_ws && p.aux_bits &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= 4096) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
@@ -435,6 +435,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.dq = dy.rowv.p; w.dq_s0 = dy.rowv.rs; w.dq_s1 = dy.rowv.cs; w.dq_sm = dy.rowv.pitch;
     w.wt = nr.base + l.w_off[l.L]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[l.L];
     w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
+    if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
     w.M = M; w.nz1 = nr.nz1;
     if (ws_dgrad_supported(w, out, in)) {

@@ -436,7 +436,8 @@ struct WsDgradP {
   const unsigned int* xbits; long xb_s0, xb_s1; int xb_g;     // mask words of the layer-0 activation (N = 256 columns)
   const float* dq; long dq_s0, dq_s1, dq_sm;                   // dLoss/dq per row
   const float* wt; long wt_s0, wt_s1;                          // w_tail [256]
-  const float* W; long w_s0, w_s1;                             // W1 (out = k, in = n) row-major [256][256]
+  const float* W; long w_s0, w_s1, w_sn, w_sk;                 // W1: element (k = output unit, n = input unit) at W[n * w_sn + k * w_sk]
+                                                               //   nn.Linear (out, in): w_sn = 1, w_sk = 256; EnsembleLinear (in, out): 256, 1
   const float* X; long x_s0, x_s1; int x_pitch, in0;           // layer-0 input rows [M][x_pitch], in0 + 1 <= 32
   float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
@@ -470,7 +471,10 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       const f32x4 t0 = *(const f32x4*)&wtg[k0], t1 = *(const f32x4*)&wtg[k0 + 4];
       f32x4 a, b;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { a[j] = t0[j] * Wg[(long)(k0 + j) * WS_N + n]; b[j] = t1[j] * Wg[(long)(k0 + 4 + j) * WS_N + n]; }
+      for (int j = 0; j < 4; ++j) {
+        a[j] = t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
+        b[j] = t1[j] * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
+      }
       ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
     }
   // zero both X^T images once (rows c >= x_pitch are never written again)

@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dW, hW.data(), 4 * 65536L * nz, hipMemcpyHostToDevice)); CK(hipMemcpy(dX, hX.data(), 4L * M * xp * nz, hipMemcpyHostToDevice));
   WsDgradP p; memset(&p, 0, sizeof(p));
   p.abits = dab; p.ab_s1 = (long)M * 8; p.ab_g = 8; p.xbits = dxb; p.xb_s1 = (long)M * 8; p.xb_g = 8;
-  p.dq = ddq; p.dq_s1 = M; p.dq_sm = 1; p.wt = dwt; p.wt_s1 = 256; p.W = dW; p.w_s1 = 65536; p.X = dX; p.x_s1 = (long)M * xp; p.x_pitch = xp; p.in0 = in0;
+  p.dq = ddq; p.dq_s1 = M; p.dq_sm = 1; p.wt = dwt; p.wt_s1 = 256; p.W = dW; p.w_s1 = 65536; p.w_sn = 1; p.w_sk = 256; p.X = dX; p.x_s1 = (long)M * xp; p.x_pitch = xp; p.in0 = in0;
   p.w0_out = dG; p.b0_out = dG + 256 * in0; p.o_s1 = (long)SL * P; p.ob_s1 = (long)SL * P; p.o_ks = P; p.o_sr = in0; p.M = M; p.nz1 = nz;
   if (!ws_dgrad_supported(p, 256, 256)) { printf("not supported\n"); return 1; }
   const int per_z = ws_dgrad_blocks(M, nz, SL);
