@@ -168,9 +168,23 @@ CQL_CASES = {
 }
 
 
+# Shapes that are checked against the oracle only (no reference fixture): they exercise kernel-selection corners of the HIP engine
+CQL_EXTRA_CASES = {
+    # 111-dimensional observations (Ant-like): the first layer is too wide to be fused into the weight-stationary forward
+    "cql_wide_obs": dict(obs_dim=111, act_dim=8, hidden=[256, 256], B=256, N=10, steps=3, seed=301, over={}),
+    # max-Q backup at full size: the target critics see B*N rows
+    "cql_halfcheetah_maxq": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, N=10, steps=3, seed=302, over=dict(max_q_backup=True)),
+    # Lagrange variant + stochastic backup at full size
+    "cql_halfcheetah_lagrange": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, N=10, steps=3, seed=303,
+                                     over=dict(with_lagrange=True, deterministic_backup=False)),
+    # batch size that is not a multiple of 32 (row groups of the weight-stationary kernels): everything stays on the tiled kernels
+    "cql_batch_200": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=200, N=10, steps=3, seed=304, over={}),
+}
+
+
 def cql_case_inputs(case):
     """(cfg_overrides, init_state, [batch_k], [noise_k]) for a CQL case."""
-    c = CQL_CASES[case]
+    c = CQL_CASES[case] if case in CQL_CASES else CQL_EXTRA_CASES[case]
     rng = np.random.RandomState(c["seed"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
     state = OrderedDict()

@@ -15,7 +15,7 @@ NETS = {"actor": 0, "critic1": 1, "critic2": 2, "critic1_old": 3, "critic2_old":
 def make_engine(case, n_runs=1, precision=0):
     from offlinerlkit import _engine
     cfg, st, batches, noises = cql_oracle_setup(case)
-    c = synth.CQL_CASES[case]
+    c = synth.CQL_CASES[case] if case in synth.CQL_CASES else synth.CQL_EXTRA_CASES[case]
     over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs,
                 num_repeat_actions=c["N"], target_entropy=cfg["target_entropy"], auto_alpha=int(cfg["auto_alpha"]),
                 alpha=cfg["alpha"], max_q_backup=int(cfg["max_q_backup"]), deterministic_backup=int(cfg["deterministic_backup"]),
@@ -160,6 +160,27 @@ def test_cql_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
                 assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < 2e-3, (nm, pn)
     finally:
         eng4.close(); eng1.close()
+
+
+@pytest.mark.parametrize("case", list(synth.CQL_EXTRA_CASES) + ["cql_halfcheetah_h3"])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_cql_many_runs_kernel_selection_corners(case, precision):
+    """Four runs per engine on shapes that steer the kernel selection: observations too wide for the fused first layer, B*N target
+    rows (max-Q backup), the Lagrange / stochastic-backup variant, a batch that is not a multiple of the 32-row groups, three hidden
+    layers.  Oracle-only parity (no reference fixture for these shapes): losses within 1e-4 for every run over three steps."""
+    from oracle import cql as ocql
+    R = 4
+    eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    try:
+        keys = eng.metric_names
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            res, _ = ocql.learn(st, cfg, b, n)
+            m = eng.step(lead(b, R), lead(noise_list(n), R))
+            ora = np.array([res[x] for x in keys])
+            for r in range(R):
+                assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (case, precision, k, r, m[r], ora)
+    finally:
+        eng.close()
 
 
 def test_cql_learn_n_device_sampling_runs_and_is_finite():
