@@ -257,7 +257,7 @@ def main():
     value = total_steps / dt
     out = None
     single = None
-    if rank == 0 and not args.no_single and R > 1:
+    if rank == 0 and world == 1 and not args.no_single and (R > 1 or E > 1):
         # side measurement: the same workload with ONE run on the GPU (latency-bound regime), same precision
         cfg1 = _engine.default_config("cql", obs_dim=OBS, act_dim=ACT, hidden=HIDDEN, batch_size=BATCH, n_runs=1, device=local_rank,
                                       precision=args.precision, seed=99, num_repeat_actions=NREP, target_entropy=-float(ACT))
@@ -305,7 +305,7 @@ def main():
                             step_frac_of_mlp_gemm_roofline=(value / world) * flops_step / (peak * 1e12),
                             table=[dict(name=t["name"], ms_per_step=t["total_ms"] / args.profile_steps,
                                         launches_per_step=t["launches"] / args.profile_steps) for t in table[:12]])
-        cpu = None if args.no_cpu_baseline else cpu_baseline()
+        cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {
             "metric": "gradient-steps/sec (CQL, batch=256)", "value": value, "unit": "gradient-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -320,7 +320,8 @@ def main():
             "final_metrics_rank0_run0": dict(zip(eng.metric_names, [float(x) for x in metrics[0]])),
         }
         print(json.dumps(out))
-    eng.close()
+    for g in engines:
+        g.close()
     if dist is not None:
         dist.destroy_process_group()
 
