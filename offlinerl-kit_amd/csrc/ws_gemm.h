@@ -52,11 +52,13 @@ struct WsFwdP {
 #define WS_WAVES 8      // 16 waves (16 columns each) measured slower: the 128-VGPR budget spills
 #endif
 enum { WS_ROWS = 32, WS_K = 256, WS_N = 256, WS_PITCH = WS_K, WS_NW = WS_WAVES, WS_NT = 64 * WS_NW, WS_CB = WS_N / 16 / WS_NW };   // unpadded rows: 16-byte chunks are XOR-swizzled; WS_CB 16-column blocks per wave
-enum { WS_SUB = WS_ROWS / 16, WS_LD = WS_ROWS * WS_K / 4 / WS_NT };   // 16-row blocks per group; float4 loads per thread per group
+enum { WS_SUB = WS_ROWS / 16, WS_LD = WS_ROWS * WS_K / 4 / WS_NT };
+enum { WS_NBP = 68, WS_XLP = 36 };      // byte pitch of a mask-nibble row (64 used) / float pitch of a narrow-input row (32 used): odd multiples of 4 B / 16 B spread the rows over the banks   // 16-row blocks per group; float4 loads per thread per group
 // LDS: A image [2 buffers][hi, lo][WS_ROWS][256] bf16 (swizzled) + tail partial sums [2][WS_NW waves][WS_ROWS] floats
 //      + ReLU-mask nibbles [2][WS_ROWS][64] bytes
 static constexpr size_t ws_fwd_lds_bytes(bool l0 = false) {
-  return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * 64 + (l0 ? sizeof(float) * 2 * WS_ROWS * 32 + 2 * WS_ROWS * 64 : 0);
+  return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * WS_NBP +
+         (l0 ? sizeof(float) * 2 * WS_ROWS * WS_XLP + 2 * WS_ROWS * WS_NBP : 0);
 }
 
 __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
@@ -73,8 +75,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
   float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
   unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
-  float* Xl = (float*)(nbs + 2 * WS_ROWS * 64);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
-  unsigned char* nbs0 = (unsigned char*)(Xl + 2 * WS_ROWS * 32);         // L0: mask nibbles of the produced h0
+  float* Xl = (float*)(nbs + 2 * WS_ROWS * WS_NBP);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
+  unsigned char* nbs0 = (unsigned char*)(Xl + 2 * WS_ROWS * WS_XLP);         // L0: mask nibbles of the produced h0
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   auto storeX = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      if (tid + WS_NT * i < xe) Xl[(buf * WS_ROWS + xr[i]) * 32 + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];
+      if (tid + WS_NT * i < xe) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];
   };
   // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
   auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
       const int r = 16 * s + li;
-      const float* xrow = Xl + (xbuf * WS_ROWS + r) * 32 + 8 * lq;
+      const float* xrow = Xl + (xbuf * WS_ROWS + r) * WS_XLP + 8 * lq;
       bf16x8 xah, xal;
       ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
       const long m = (long)g * WS_ROWS + r;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
         const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
         *(bf16x4*)(dh + o) = h;
         *(bf16x4*)(dl + o) = l;
-        nbs0[(par * WS_ROWS + r) * 64 + (k >> 2)] =
+        nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
             (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
       }
     }
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   auto finish0 = [&](int g, int par) __attribute__((always_inline)) {  // after the barrier that follows produce(g): pack the h0 mask
     if (tid < WS_ROWS * 8) {
       const int row = tid >> 3, wd = tid & 7;
-      const unsigned int* nb = (const unsigned int*)(nbs0 + (par * WS_ROWS + row) * 64 + 8 * wd);
+      const unsigned int* nb = (const unsigned int*)(nbs0 + (par * WS_ROWS + row) * WS_NBP + 8 * wd);
       const unsigned int d0 = nb[0], d1 = nb[1];
       const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
       const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const int g0 = blockIdx.x, gs = gridDim.x;
   if (g0 >= p.groups) return;
   if (L0) {
-    for (int e = tid; e < 2 * WS_ROWS * 32; e += WS_NT) Xl[e] = 0.f;   // columns >= x0_pitch stay zero
+    for (int e = tid; e < 2 * WS_ROWS * WS_XLP; e += WS_NT) Xl[e] = 0.f;   // columns >= x0_pitch stay zero
     loadX(g0);
     __syncthreads();
     storeX(0);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #endif
         part += (v[0] * twq[cb][0] + v[1] * twq[cb][1]) + (v[2] * twq[cb][2] + v[3] * twq[cb][3]);
         // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
-        nbs[(par * WS_ROWS + 16 * s + li) * 64 + 4 * WS_CB * wave + 4 * cb + lq] =
+        nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
             (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
       }
       if (TQ) {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     if (DG) return;
     if (tid < WS_ROWS * 8) {                         // thread (row, word): eight nibbles -> one 32-column mask word
       const int row = tid >> 3, wd = tid & 7, m = g * WS_ROWS + row;
-      const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * 64 + 8 * wd);
+      const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * WS_NBP + 8 * wd);
       const unsigned int d0 = nb[0], d1 = nb[1];
       const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
       const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
@@ -443,14 +445,15 @@ struct WsDgradP {
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
   int M, nz1, groups;
 };
-static constexpr size_t ws_dgrad_lds_bytes() { return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WS_ROWS * 2; }
+enum { WD_XP = WS_ROWS + 4 };                                       // bf16 pitch of an X^T row (72 B: scattered 2-byte stores and 8-byte reads spread over the banks)
+static constexpr size_t ws_dgrad_lds_bytes() { return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WD_XP * 2; }
 
 template <bool W0, bool STORE>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
-  __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][m = 32]: X^T of the row group
+  __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
     }
   // zero both X^T images once (rows c >= x_pitch are never written again)
-  if (W0) for (int e = tid; e < 2 * 2 * 32 * WS_ROWS / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
+  if (W0) for (int e = tid; e < 2 * 2 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
   __syncthreads();
 
   // ---- staging of one row group: thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     __bf16* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
-    __bf16* xt = XT + (long)buf * 2 * 32 * WS_ROWS;
+    __bf16* xt = XT + (long)buf * 2 * 32 * WD_XP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + WS_NT * i;
@@ -517,8 +520,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
         const int rr = e / p.x_pitch, c = e - rr * p.x_pitch;
         const float x = (c == p.in0) ? 1.0f : sx[i];
         const __bf16 hh = (__bf16)x;
-        xt[c * WS_ROWS + rr] = hh;
-        xt[32 * WS_ROWS + c * WS_ROWS + rr] = (__bf16)(x - (float)hh);
+        xt[c * WD_XP + rr] = hh;
+        xt[32 * WD_XP + c * WD_XP + rr] = (__bf16)(x - (float)hh);
       }
     }
   };
@@ -567,16 +570,16 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       }
     }
     // dz0 block -> (hi, lo) bf16 B operand of the 16x16x16 MFMA; A operand = X^T rows c, columns m = 16 s + 4 lq ..
-    const __bf16* xth = XT + (long)buf * 2 * 32 * WS_ROWS;
-    const __bf16* xtl = xth + 32 * WS_ROWS;
+    const __bf16* xth = XT + (long)buf * 2 * 32 * WD_XP;
+    const __bf16* xtl = xth + 32 * WD_XP;
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
       s16x4 xh[2], xl[2];
       if (W0) {
 #pragma unroll
         for (int cbk = 0; cbk < 2; ++cbk) {
-          xh[cbk] = *(const s16x4*)&xth[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
-          xl[cbk] = *(const s16x4*)&xtl[(16 * cbk + li) * WS_ROWS + 16 * s + 4 * lq];
+          xh[cbk] = *(const s16x4*)&xth[(16 * cbk + li) * WD_XP + 16 * s + 4 * lq];
+          xl[cbk] = *(const s16x4*)&xtl[(16 * cbk + li) * WD_XP + 16 * s + 4 * lq];
         }
       }
 #pragma unroll
