@@ -32,6 +32,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 
 namespace orl {
 
@@ -772,11 +773,11 @@ static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   if (EPI == E_MASK && p.w0_out) lds = std::max(lds, sizeof(float) * ((size_t)CFG::TM * (CFG::TN + 4) + (size_t)CFG::TM * W0_XP));
   auto kern = gemm16_kernel<CFG, LA, LB, PA, PB, EPI, PREC>;
   if (lds > 64 * 1024) {
-    static bool raised = false;   // one flag per instantiation
-    if (!raised) {
+    static std::atomic<size_t> raised_to{0};   // per instantiation; the request can grow (fused layer-0 gradient), engines may launch from several threads
+    if (lds > raised_to.load(std::memory_order_acquire)) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      raised = true;
+      raised_to.store(lds, std::memory_order_release);
     }
   }
   hipLaunchKernelGGL(kern, grid, block, lds, st, p);

@@ -201,12 +201,9 @@ static inline hipError_t launch_fused_fwd_inst(const FusedFwdP& p, int nz, hipSt
   constexpr size_t lds = (PREC == P_F32) ? sizeof(float) * ((size_t)TM * (H + 4) + 2 * H * (TK + 4))
                                          : 2 * ((size_t)2 * TM * (H + 8) + 2 * 2 * H * (TK + 8));
   auto kern = mlp_fwd_kernel<WM, WN, MA, NB, PREC>;
-  static bool raised = false;
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
+  static const hipError_t attr_err =      // thread-safe one-time initialisation, one per instantiation
+      hipFuncSetAttribute((const void*)mlp_fwd_kernel<WM, WN, MA, NB, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr_err != hipSuccess) return attr_err;
   dim3 grid((p.M + TM - 1) / TM, 1, nz);
   hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
   return hipGetLastError();

@@ -393,17 +393,16 @@ static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   if (per_z > p.groups) per_z = p.groups;
   const bool l0 = p.X0 != nullptr;
   const size_t lds = ws_fwd_lds_bytes(l0);
-  static bool raised = false;
-  if (!raised) {
+  static const hipError_t attr_err = [] {       // thread-safe one-time initialisation (engines may launch from several host threads)
     const int big = (int)ws_fwd_lds_bytes(true);
     hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 1, nz), block(WS_NT);
   if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true>), grid, block, lds, st, p);
   else if (l0) {
@@ -905,13 +904,12 @@ static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
 }
 static inline hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
-  static bool raised = false;
-  if (!raised) {
+  static const hipError_t attr_err = [] {
     hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
-    if (e != hipSuccess) return e;
-    raised = true;
-  }
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
   if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
   else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
   return hipGetLastError();
