@@ -123,6 +123,7 @@ struct Engine {
   std::vector<void*> allocs;
   std::map<std::string, Mat> ws;
   std::map<std::string, long> ws_len;
+  std::set<const void*> vals_dead;   // activations whose VALUES the forward pass did not store (mask bits only); consumers of the values fail
   std::set<const void*> bits_live;   // mask-bit buffers whose producer launch emitted them this step (decided on the host)
   struct Tap { Mat m; long rows; int cols; };
   std::map<std::string, Tap> taps;
@@ -144,6 +145,8 @@ struct Engine {
   bool force_scalar = false;   // debug: disable the vector loaders
   int loss_nblk = 1;
   bool use_fused = false;      // fused multi-layer forward kernel (csrc/mlp_fused.h), opt-in with ORL_FUSED=1
+  bool elide_top = true;       // many-row single-output nets: keep the top hidden activation out of HBM (ORL_WS_KEEP_H1=1 stores it)
+  long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
 
   ~Engine();

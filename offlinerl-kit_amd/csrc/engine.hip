@@ -279,6 +279,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   p.M = M; p.N = out; p.K = in_rows;
   const bool a_kpad = X.pitch >= ((in_rows + 3) & ~3);   // input matrices are zero-padded to 16 B rows
   p.nz1 = nr.nz1; p.ksplit = 1;
+  vals_dead.erase(Y.p);
   p.bias = {nr.base + l.b_off[layer], nr.rs, l.b_ms[layer]};
   if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
   const int nz = R * nr.nz1;
@@ -302,6 +303,10 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       w.tb = nr.base + l.b_off[l.L]; w.tb_s0 = nr.rs; w.tb_s1 = l.b_ms[l.L];
       w.tq = tail_out->p; w.tq_s0 = tail_out->rs; w.tq_s1 = tail_out->cs; w.tq_sm = tail_out->pitch;
     }
+    // With the single-output tail folded in, the backward pass of a many-row batch needs only the mask bits of this activation
+    // (ws_dgrad_w0 / ws_wgrad's derived tail gradients): the activation itself then never goes to HBM.
+    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows;
+    if (elide) w.Y = nullptr;
     const bool ws_ok = ws_fwd_supported(w, in, out);
     bool fused0 = false;
     if (ws_ok && fuse_X0 && layer == 1 && X.bits && X.pitch == in) {
@@ -320,12 +325,13 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     if (ws_ok) {
       const double f0 = fused0 ? 2.0 * M * (double)in * (w.in0 + 1) * nz : 0.0;
       prof_begin(tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
-                 4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (double)M * in + (double)out * in + (double)M * out));
+                 4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (double)M * in + (double)out * in + (elide ? (double)M * out / 32 : (double)M * out)));
       if (fused0) bits_live.insert(X.bits);
       hipError_t err = launch_ws_fwd(w, nz, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
       bits_live.insert(Y.bits);
+      if (elide) vals_dead.insert(Y.p);
       if (tail_fused) *tail_fused = want_tail;
       return 0;
     }
@@ -497,6 +503,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
         return 0;
       }
     }
+    if (vals_dead.count(dy.m.p)) return fail(std::string("dgrad ") + tag + ": the activation values were not stored by the forward pass");
     if (maskH) return run_gemm<PA_RANK1, PB_PLAIN, E_MASK>(this, CFG_AUTO, p, nz, tag);
     return run_gemm<PA_RANK1, PB_PLAIN, E_PLAIN>(this, CFG_AUTO, p, nz, tag);
   }
@@ -531,6 +538,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
   if (slab0 + ksplit > max_slab) return fail("wgrad: slab budget exceeded");
+  if (vals_dead.count(X.p)) return fail(std::string("wgrad ") + tag + ": the input activation was not stored by the forward pass");
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
@@ -559,7 +567,8 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   // the tail layer's gradients ride along (*fuse_tail = true, same slabs)
   if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && in_row0 == 0 && in_rows == in && X.pitch == in &&
-      (long)M * nz >= 40000) {
+      (long)M * nz >= ws_wgrad_min_rows) {
+    const bool derived = vals_dead.count(dy.m.p) > 0;
     WsWgradP w;
     memset(&w, 0, sizeof(w));
     w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
@@ -569,12 +578,17 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
     // the activation values are streamed through registers as well: tail-layer gradients (and db) from the same pass, same slabs
-    w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch;
+    // (or, when the forward pass did not store h1, derived from the accumulators: see WsWgradP)
+    if (derived) {
+      w.W1 = nr.base + l.w_off[layer]; w.w1_s0 = nr.rs; w.w1_s1 = l.w_ms[layer];
+      w.b1 = nr.base + l.b_off[layer]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[layer];
+    } else { w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch; }
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
     w.M = M; w.nz1 = nr.nz1;
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab);
-      prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz, nz * (4.0 * M * (double)out + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
+      prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
+                 nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
@@ -583,6 +597,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       return 0;
     }
   }
+  if (dy.rank1 && vals_dead.count(dy.m.p)) return fail(std::string("wgrad ") + tag + ": the activation values were not stored by the forward pass");
   if (fuse_tail) {
     // the rank-1 kernel streams h and dq anyway: let it also emit the tail layer's dw / db (same split-K slabs)
     *fuse_tail = dy.rank1 && rank1_wgrad_is_fast(p, force_scalar);
@@ -810,6 +825,8 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
   { const char* f = getenv("ORL_FUSED"); use_fused = f && atoi(f) != 0; }
+  { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
+  { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }   // opt-in: measured slower than the layer-wise kernels
   if (build_common()) return -1;
   int rc = -1;

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   // WS_ROWS), so the scheduler can pair every MFMA with the VALU / store work of the other stage.  Then group g + gs is staged
   // from register set (it + 1) & 1.
   const float* __restrict__ twg2 = twg;
+  const bool storeY = !TQ || p.Y != nullptr;       // a single-output net whose backward needs only the mask bits of this activation
   auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
     float* qsw = qs + (par * WS_NW + wave) * WS_ROWS;
     if (DG) {                                      // gradient epilogue: ReLU mask of the receiving activation from its packed bits
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
 #ifndef WS_LAB_NO_STORE
-        *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+        if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
 #else
         if (v[0] == 12345.678f) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
 #endif
@@ -374,6 +375,7 @@ static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
   if (p.w_sk == 1 && (!aligned16(p.W) || (p.w_s0 & 3) || (p.w_s1 & 3) || (p.w_sn & 3))) return false;
   if (p.dmask) { if (p.tq || p.X0 || p.dm_g != 8) return false; }
   else if (!aligned16(p.bias) || (p.b_s0 & 3) || (p.b_s1 & 3)) return false;
+  if (!p.Y && (!p.tq || !p.mb)) return false;      // the activation may stay unstored only when the tail is folded in
   if (!aligned16(p.Y) || (p.y_pitch & 3) || (p.y_s0 & 3) || (p.y_s1 & 3)) return false;
   if (p.tq && (!aligned16(p.tw) || (p.tw_s0 & 3) || (p.tw_s1 & 3))) return false;
   return true;
@@ -670,6 +672,11 @@ struct WsWgradP {
   //   dw_tail[k] = sum_m dq[m] h1[m][k],  db_tail = sum_m dq[m];  db1 then comes from the same pass (no MFMA operand for it)
   const float* H1; long h1_s0, h1_s1; int h1_pitch;
   float *dwt, *dbt; long o_s1wt, o_s1bt;
+  // DERIVED variant (H1 == nullptr, W1 != nullptr): h1 was never stored.  With G[n][k] = sum_m dq[m] 1[h1[m][n] > 0] h0[m][k] (the
+  // accumulators before the w_tail scaling) and g[n] = sum_m dq[m] 1[h1[m][n] > 0], h1 = relu(h0 W1^T + b1) gives
+  //   dw_tail[n] = sum_m dq[m] h1[m][n] = sum_k W1[n][k] G[n][k] + b1[n] g[n]      (linear in G, so it holds per slab)
+  const float* W1; long w1_s0, w1_s1;                          // [256][256] (out, in) row-major
+  const float* b1; long b1_s0, b1_s1;
   int M, nz1, groups;
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
@@ -687,9 +694,10 @@ __device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
 }
 
-template <bool TAILS>
+template <int MODE>      // 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
+  constexpr bool TAILS = (MODE == 1);
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* img = (__bf16*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
@@ -772,6 +780,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       const __bf16 hh = (__bf16)sdq[i];
       __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
       dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = (__bf16)(sdq[i] - (float)hh);
+      if (MODE == 2) dqsum += sdq[i];
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
@@ -864,6 +873,44 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
   }
+  if (MODE == 2) {
+    // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
+    // group and then the 8 waves (= all 256 input columns) are summed in a fixed order
+    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
+    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * kb + 4 * lq + r;
+        float t = W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        if (li == 0) red[wave * WS_K + o] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r];
+    }
+    if (lane == 0) red[9 * WS_K + wave] = dqsum;
+    __syncthreads();
+    if (tid < WS_K) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[w * WS_K + tid];
+      const float gs1 = red[8 * WS_K + tid];
+      p.dwt[so + z1 * p.o_s1wt + tid] = a + (p.b1 + z0 * p.b1_s0 + z1 * p.b1_s1)[tid] * gs1;
+      db[tid] = wtg[tid] * gs1;
+    }
+    if (tid == 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[9 * WS_K + w];
+      p.dbt[so + z1 * p.o_s1bt] = a;
+    }
+    return;
+  }
   if (!TAILS) {
     if (li == 0) {
 #pragma unroll
@@ -899,19 +946,22 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.abits || p.ab_g != 8) return false;
   if (!aligned16(p.H0) || (p.h0_pitch & 3) || (p.h0_s0 & 3) || (p.h0_s1 & 3)) return false;
+  if (!p.H1 && p.W1 && (!p.b1 || !p.dwt || !p.dbt)) return false;
   if (p.H1 && (!aligned16(p.H1) || (p.h1_pitch & 3) || (p.h1_s0 & 3) || (p.h1_s1 & 3) || !p.dwt || !p.dbt)) return false;
   return aligned16(p.wt) && !(p.wt_s0 & 3) && !(p.wt_s1 & 3);
 }
 static inline hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
   static const hipError_t attr_err = [] {
-    hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
-  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<true>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
-  else hipLaunchKernelGGL(ws_wgrad_kernel<false>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<1>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  else if (p.W1) hipLaunchKernelGGL(ws_wgrad_kernel<2>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_wgrad_kernel<0>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
   return hipGetLastError();
 }
 

@@ -135,6 +135,53 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
         eng.close()
 
 
+def test_cql_bench_sized_engine_follows_the_oracle():
+    """96 full-size runs per engine in split-bf16 precision (bench.py's default engine): 192 batched critics -> one workgroup per
+    critic in the weight-stationary kernels, top hidden activation not stored, tail gradients derived in the wgrad.  Identical
+    inputs for all runs; first, middle and last run must follow the oracle over three steps (the later steps see the updated
+    parameters, i.e. the gradients of the earlier ones)."""
+    from oracle import cql as ocql
+    case = "cql_halfcheetah"
+    R = 96
+    eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
+    try:
+        keys = eng.metric_names
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            res, _ = ocql.learn(st, cfg, b, n)
+            m = eng.step(lead(b, R), lead(noise_list(n), R))
+            ora = np.array([res[x] for x in keys])
+            for r in (0, R // 2, R - 1):
+                assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (k, r, m[r], ora)
+            assert np.abs(m - m[0]).max() <= 1e-5 * np.abs(m[0]).max(), k      # identical inputs: the runs agree with each other
+    finally:
+        eng.close()
+
+
+def test_cql_derived_tail_gradients_match_streamed_ones(monkeypatch):
+    """The engine normally keeps the critics' top hidden activation h1 out of HBM (mask bits only) and derives
+    dw_tail = sum_k W1[n][k] G[n][k] + b1[n] g[n] from the wgrad accumulators; ORL_WS_KEEP_H1=1 stores h1 and streams it for
+    dw_tail = sum_m dq[m] h1[m][n].  Same inputs -> same losses and same updated tail parameters to rounding."""
+    case = "cql_halfcheetah"
+    R = 4
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
+    monkeypatch.setenv("ORL_WS_KEEP_H1", "1")
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=1)
+    monkeypatch.delenv("ORL_WS_KEEP_H1")
+    try:
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            ma = enga.step(lead(b, R), lead(noise_list(n), R))
+            mb = engb.step(lead(b, R), lead(noise_list(n), R))
+            assert rel_err(ma[R - 1], mb[R - 1], floor=1e-2) < 2e-5, (k, ma[R - 1], mb[R - 1])
+        for nm in ("critic1", "critic2"):
+            a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < 3e-6, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < 2e-3, (nm, pn)
+    finally:
+        enga.close(); engb.close()
+
+
 def test_cql_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
     """Split-bf16, full size: with 4 runs per engine the 256x256 critic layers go through the weight-stationary kernels
     (csrc/ws_gemm.h: forward with fused tail + mask bits, top-layer dgrad from mask bits fused with the layer-0 weight
