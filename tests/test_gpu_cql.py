@@ -136,13 +136,13 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
 
 
 def test_cql_bench_sized_engine_follows_the_oracle():
-    """96 full-size runs per engine in split-bf16 precision (bench.py's default engine): 192 batched critics -> one workgroup per
+    """128 full-size runs per engine in split-bf16 precision (bench.py's default engine): 256 batched critics -> one workgroup per
     critic in the weight-stationary kernels, top hidden activation not stored, tail gradients derived in the wgrad.  Identical
     inputs for all runs; first, middle and last run must follow the oracle over three steps (the later steps see the updated
     parameters, i.e. the gradients of the earlier ones)."""
     from oracle import cql as ocql
     case = "cql_halfcheetah"
-    R = 96
+    R = 128
     eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
     try:
         keys = eng.metric_names

@@ -8,7 +8,7 @@ import csv, glob, os, sys, collections, re
 
 
 def load(d):
-    f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)     # newest pass
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = (re.sub(r"^void orl::|\(.*$", "", r["Kernel_Name"]), int(r["Grid_Size"]))
