@@ -58,7 +58,7 @@ enum { WS_NBP = 68, WS_XLP = 36 };      // byte pitch of a mask-nibble row (64 u
 //      + ReLU-mask nibbles [2][WS_ROWS][64] bytes
 static constexpr size_t ws_fwd_lds_bytes(bool l0 = false) {
   return (size_t)2 * 2 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * WS_NBP +
-         (l0 ? sizeof(float) * 2 * WS_ROWS * WS_XLP + 2 * WS_ROWS * WS_NBP : 0);
+         (l0 ? sizeof(float) * 2 * WS_ROWS * WS_XLP + 2 * WS_ROWS * WS_NBP : 0) + sizeof(float) * 2 * WS_N;   // + bias / tail weights
 }
 
 __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
@@ -69,7 +69,7 @@ __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16
   }
 }
 
-template <bool TQ, bool L0, bool DG = false>
+template <bool TQ, bool L0, bool DG = false, bool SY = true>      // SY = false: the activation itself is not stored (TQ only)
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
   float* Xl = (float*)(nbs + 2 * WS_ROWS * WS_NBP);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
   unsigned char* nbs0 = (unsigned char*)(Xl + 2 * WS_ROWS * WS_XLP);         // L0: mask nibbles of the produced h0
+  float* cst = (float*)((char*)ws_smem + ws_fwd_lds_bytes(L0) - sizeof(float) * 2 * WS_N);   // [bias | tail weights]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
@@ -120,9 +121,11 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       ws_split8(a, b, b0h[cb], b0l[cb]);
     }
   }
-  // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r are re-read per row group (L1 hits) rather than
-  // held in 16 VGPRs next to the 128 VGPRs of resident B fragments
+  // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r sit in LDS (not in 16 VGPRs next to the 128 VGPRs of
+  // resident B fragments, and not re-read from global memory: vmcnt is in-order, so waiting for such a load in the epilogue would
+  // also wait for every activation store issued before it)
   const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
+  if (!DG && tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }      // visible after the prologue's barriers
   const float tbias = TQ ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
 
   // ---- staging of one row group: thread t moves float4 #(t + 512 i), i = 0..7, of the [64][256] tile ----
@@ -136,11 +139,16 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
     }
   };
-  auto store_group = [&](int buf, const f32x4 (&st)[WS_LD]) __attribute__((always_inline)) {
+  auto load_piece = [&](int g, f32x4 (&st)[WS_LD], int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    int m = g * WS_ROWS + r; m = m < p.M ? m : p.M - 1;
+    st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
+  };
+  auto store_group = [&](int buf, const f32x4 (&st)[WS_LD], int i0 = 0, int i1 = WS_LD) __attribute__((always_inline)) {
     __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
     __bf16* dl = dh + WS_ROWS * WS_PITCH;
 #pragma unroll
-    for (int i = 0; i < WS_LD; ++i) {
+    for (int i = i0; i < i1; ++i) {
       const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
       bf16x4 h, l;
 #pragma unroll
@@ -158,46 +166,53 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   int xr[2], xc[2];
   float sx[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0; }
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0;
+    if (L0 && e >= xe) { xr[i] = 0; xc[i] = 32; }       // never read (rows are consumed as 32 columns of the 36-float pitch)
+  }
   auto loadX = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = e < xe ? X0g[(long)g * xe + e] : 0.f; }
+    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
   };
   auto storeX = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      if (tid + WS_NT * i < xe) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];
+    for (int i = 0; i < 2; ++i) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];   // surplus threads: pad column 32
   };
   // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
-  auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
+  auto prod_x = [&](int xbuf, int s, bf16x8& xah, bf16x8& xal) __attribute__((always_inline)) {
+    const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 8 * lq;
+    ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+  };
+  auto prod_block = [&](int g, int buf, int par, int s, int cb, const bf16x8& xah, const bf16x8& xal) __attribute__((always_inline)) {
     __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
     __bf16* dl = dh + WS_ROWS * WS_PITCH;
+    const int r = 16 * s + li;
+    const long m = (long)g * WS_ROWS + r;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
+    *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)v[j]; h[j] = hh; l[j] = (__bf16)(v[j] - (float)hh); }
+    const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
+    *(bf16x4*)(dh + o) = h;
+    *(bf16x4*)(dl + o) = l;
+    nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
+        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+  };
+  auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      const int r = 16 * s + li;
-      const float* xrow = Xl + (xbuf * WS_ROWS + r) * WS_XLP + 8 * lq;
       bf16x8 xah, xal;
-      ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
-      const long m = (long)g * WS_ROWS + r;
+      prod_x(xbuf, s, xah, xal);
 #pragma unroll
-      for (int cb = 0; cb < WS_CB; ++cb) {
-        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
-        v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-        const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
-        *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
-        bf16x4 h, l;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)v[j]; h[j] = hh; l[j] = (__bf16)(v[j] - (float)hh); }
-        const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
-        *(bf16x4*)(dh + o) = h;
-        *(bf16x4*)(dl + o) = l;
-        nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
-            (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
-      }
+      for (int cb = 0; cb < WS_CB; ++cb) prod_block(g, buf, par, s, cb, xah, xal);
     }
   };
   auto finish0 = [&](int g, int par) __attribute__((always_inline)) {  // after the barrier that follows produce(g): pack the h0 mask
@@ -235,10 +250,32 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   // (accumulators `pacc`) runs in the shadow of those MFMAs -- both are in one basic block (no row guards: M is a multiple of
   // WS_ROWS), so the scheduler can pair every MFMA with the VALU / store work of the other stage.  Then group g + gs is staged
   // from register set (it + 1) & 1.
-  const float* __restrict__ twg2 = twg;
-  const bool storeY = !TQ || p.Y != nullptr;       // a single-output net whose backward needs only the mask bits of this activation
+  constexpr bool storeY = SY;                      // false: a single-output net whose backward needs only the mask bits of this activation
+  // one 16 x 16 block of the (non-gradient) epilogue: bias, ReLU, optional store, tail partial sum, 4 mask bits -> LDS
+  auto epi_block = [&](const f32x4& a, int g, int par, int s, int cb, float& part) __attribute__((always_inline)) {
+    const f32x4 bq = *(const f32x4*)&cst[ncol0 + 16 * cb + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol0 + 16 * cb + 4 * lq];
+    const int m = g * WS_ROWS + 16 * s + li;
+    f32x4 v = a + bq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+#ifndef WS_LAB_NO_STORE
+    if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+#else
+    if (v[0] == 12345.678f) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+#endif
+    part += (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
+    // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
+    nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
+        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+  };
+  auto epi_row = [&](int par, int s, float part) __attribute__((always_inline)) {
+    if (TQ) {
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      (qs + (par * WS_NW + wave) * WS_ROWS)[16 * s + li] = part;   // all four lq lanes hold the same sum: no divergent branch in this block
+    }
+  };
   auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
-    float* qsw = qs + (par * WS_NW + wave) * WS_ROWS;
     if (DG) {                                      // gradient epilogue: ReLU mask of the receiving activation from its packed bits
       static_assert(!DG || WS_CB == 2, "one 32-column mask word per wave");
       const unsigned int* __restrict__ dm = p.dmask + z0 * p.dm_s0 + z1 * p.dm_s1;
@@ -257,36 +294,12 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       }
       return;
     }
-    f32x4 bq[WS_CB], twq[WS_CB];
-#pragma unroll
-    for (int cb = 0; cb < WS_CB; ++cb) {
-      bq[cb] = *(const f32x4*)&bg[ncol0 + 16 * cb + 4 * lq];
-      twq[cb] = *(const f32x4*)&twg2[ncol0 + 16 * cb + 4 * lq];
-    }
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      const int m = g * WS_ROWS + 16 * s + li;
       float part = 0.f;
 #pragma unroll
-      for (int cb = 0; cb < WS_CB; ++cb) {
-        f32x4 v = acc[s][cb] + bq[cb];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-#ifndef WS_LAB_NO_STORE
-        if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
-#else
-        if (v[0] == 12345.678f) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
-#endif
-        part += (v[0] * twq[cb][0] + v[1] * twq[cb][1]) + (v[2] * twq[cb][2] + v[3] * twq[cb][3]);
-        // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
-        nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
-            (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
-      }
-      if (TQ) {
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (lq == 0) qsw[16 * s + li] = part;
-      }
+      for (int cb = 0; cb < WS_CB; ++cb) epi_block(acc[s][cb], g, par, s, cb, part);
+      epi_row(par, s, part);
     }
   };
   auto finish = [&](int g, int par) __attribute__((always_inline)) {   // after the barrier that follows epilogue(g)
@@ -310,7 +323,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   };
 
   f32x4 pacc[WS_SUB][WS_CB];
-  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first) __attribute__((always_inline)) {
+  // steady = true: groups g + gs .. g + 3 gs exist, so the body has no conditionals (one basic block up to the barrier)
+  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
     const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
     const __bf16* al = ah + WS_ROWS * WS_PITCH;
@@ -319,8 +333,36 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
       for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#ifdef WS_LAB_NO_FINE
+    const bool fine = false;
+#else
+    const bool fine = steady && !DG;
+#endif
+    float fpart = 0.f;
+    bf16x8 fxah, fxal;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
+#ifndef WS_LAB_NO_INTERLEAVE
+      bf16x8 fah2[WS_SUB], fal2[WS_SUB];
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const int o = (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3);
+        fah2[s] = *(const bf16x8*)&ah[o]; fal2[s] = *(const bf16x8*)&al[o];
+      }
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fal2[s], acc[s][cb], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+      if (false)
+#endif
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
         const int o = (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3);
@@ -336,30 +378,67 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #endif
         }
       }
+      if (fine) {
+        // Steady state: the work of the other pipeline stages is cut into eight pieces, one per k step, and fenced together
+        // with that step's 12 MFMAs -- the default scheduler otherwise clusters all 96 MFMAs and the matrix pipe idles during
+        // the epilogue / staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue;
+        // 4..7: the four blocks of the next group's first layer (or the four staging pieces of the plain variant).
+        static_assert(WS_SUB == 2 && WS_CB == 2 && WS_LD == 4, "eight pieces");
+        const int par = (it - 1) & 1;
+        if (ks < 4) {
+          const int s = ks >> 1, cb = ks & 1;
+          if (cb == 0) fpart = 0.f;
+          epi_block(pacc[s][cb], g - gs, par, s, cb, fpart);
+          if (cb == 1) epi_row(par, s, fpart);
+        } else if (L0) {
+          const int s = (ks - 4) >> 1, cb = (ks - 4) & 1;
+          if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxal);
+          prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxal);
+        } else {
+          store_group(buf ^ 1, stn, ks - 4, ks - 3);
+          load_piece(g + 2 * gs, stn, ks - 4);
+        }
+#ifdef WS_FINE_SGB
+#pragma unroll
+        for (int i = 0; i < 12 + ((L0 && ks >= 4) ? 3 : 0); ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, WS_FINE_SGB, 0);
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (!first) epilogue(pacc, g - gs, (it - 1) & 1);
-    if (L0) {
-      // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
-      if (g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
-      if (g + 2 * gs < p.groups) storeX(it & 1);
-      if (g + 3 * gs < p.groups) loadX(g + 3 * gs);
+    if (fine) {
+      if (L0) { storeX(it & 1); loadX(g + 3 * gs); }
     } else {
-      if (g + gs < p.groups) store_group(buf ^ 1, stn);
-      if (g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+      if (!first) epilogue(pacc, g - gs, (it - 1) & 1);
+      if (L0) {
+        // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
+        if (steady || g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
+        if (steady || g + 2 * gs < p.groups) storeX(it & 1);
+        if (steady || g + 3 * gs < p.groups) loadX(g + 3 * gs);
+      } else {
+        if (steady || g + gs < p.groups) store_group(buf ^ 1, stn);
+        if (steady || g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+      }
     }
     __syncthreads();
     if (!first) finish(g - gs, (it - 1) & 1);
-    if (L0 && g + gs < p.groups) finish0(g + gs, (it + 1) & 1);
+    if (L0 && (steady || g + gs < p.groups)) finish0(g + gs, (it + 1) & 1);
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
       for (int cb = 0; cb < WS_CB; ++cb) pacc[s][cb] = acc[s][cb];
   };
   int g = g0, it = 0;
-  iteration(g, it, st0, true);
+  iteration(g, it, st0, true, false);
   g += gs; ++it;
+  while (g + 3 * gs < p.groups) {
+    iteration(g, it, st0, false, true);
+    g += gs; ++it;
+  }
   while (g < p.groups) {
-    iteration(g, it, st0, false);
+    iteration(g, it, st0, false, false);
     g += gs; ++it;
   }
   // drain: the last group's epilogue
@@ -402,16 +481,20 @@ static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 1, nz), block(WS_NT);
   if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true>), grid, block, lds, st, p);
   else if (l0) {
-    if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((ws_fwd_kernel<false, true>), grid, block, lds, st, p);
   } else {
-    if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false>), grid, block, lds, st, p);
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, false, false, false>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((ws_fwd_kernel<false, false>), grid, block, lds, st, p);
   }
   return hipGetLastError();

@@ -49,8 +49,10 @@ int main(int argc, char** argv) {
             p.mb0 = dmb0; p.mb0_s1 = (long)M * 8; p.mb0_g = 8; if (!ws_fwd01_supported(p)) { printf("l0 not supported\n"); return 1; } }
   if (!ws_fwd_supported(p, 256, 256)) { printf("not supported\n"); return 1; }
   CK(launch_ws_fwd(p, nz, 0)); CK(hipDeviceSynchronize());
+  const bool noY = argc > 4 && atoi(argv[4]) == 1;      // time (and re-check q / mask bits of) the variant that does not store Y
+  std::vector<float> q; std::vector<unsigned> mb;
   if (check) {
-    std::vector<float> Y(nX * nz), q((long)M * nz); std::vector<unsigned> mb((long)M * 8 * nz);
+    std::vector<float> Y(nX * nz); q.resize((long)M * nz); mb.resize((long)M * 8 * nz);
     CK(hipMemcpy(Y.data(), dY, 4 * nX * nz, hipMemcpyDeviceToHost)); CK(hipMemcpy(q.data(), dq, 4L * M * nz, hipMemcpyDeviceToHost));
     CK(hipMemcpy(mb.data(), dmb, 4L * M * 8 * nz, hipMemcpyDeviceToHost));
     double eY = 0, eq = 0, sY = 0, sq = 0; long badbits = 0, nearzero = 0;
@@ -76,6 +78,16 @@ int main(int argc, char** argv) {
         if ((((m0[row * 8 + (n >> 5)] >> (n & 31)) & 1u) != 0) != (H0[i] > 0.f)) ++bad0; }
       printf("fused layer 0: max|dh0|=%.3e  h0 mask bits inconsistent: %ld\n", e0, bad0); }
     printf("M=%d nz=%d  max|dY|=%.3e (scale %.3f)  max|dq|=%.3e (scale %.3f)  mask bits inconsistent with stored Y: %ld\n", M, nz, eY, sY, eq, sq, badbits);
+  }
+  if (noY) {
+    p.Y = nullptr;
+    if (check) {
+      CK(hipMemset(dq, 0, 4L * M * nz)); CK(hipMemset(dmb, 0, 4L * M * 8 * nz));
+      CK(launch_ws_fwd(p, nz, 0)); CK(hipDeviceSynchronize());
+      std::vector<float> q2((long)M * nz); std::vector<unsigned> mb2((long)M * 8 * nz);
+      CK(hipMemcpy(q2.data(), dq, 4L * M * nz, hipMemcpyDeviceToHost)); CK(hipMemcpy(mb2.data(), dmb, 4L * M * 8 * nz, hipMemcpyDeviceToHost));
+      printf("no-Y variant: q identical %d, mask bits identical %d\n", (int)(memcmp(q.data(), q2.data(), 4L * M * nz) == 0), (int)(memcmp(mb.data(), mb2.data(), 4L * M * 8 * nz) == 0));
+    }
   }
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   for (int i = 0; i < 3; ++i) CK(launch_ws_fwd(p, nz, 0));
