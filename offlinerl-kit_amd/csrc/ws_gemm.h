@@ -573,13 +573,23 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   float sx[2];
   const int xe = W0 ? WS_ROWS * p.x_pitch : 0;                       // X elements of a row group (<= 1024)
   float* __restrict__ Cg = STORE ? p.C + z0 * p.c_s0 + z1 * p.c_s1 : nullptr;
+  // X element e = tid + 512 i of a row group -> X^T position (column c, row rr); surplus threads use a pad slot that is never read
+  // (rows are consumed as 32 of the WD_XP entries); computed once: no division and no predication inside the loop
+  int xo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    int rr = W0 ? e / (W0 ? p.x_pitch : 1) : 0, c = W0 ? e - rr * p.x_pitch : 0;
+    if (e >= xe) { rr = 32; c = 0; }
+    xo[i] = ((c == p.in0) ? (1 << 16) : 0) | (c * WD_XP + rr);        // bit 16: the ones column (bias gradient)
+  }
   auto load_group = [&](int g) __attribute__((always_inline)) {
     sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
     if (W0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int e = tid + WS_NT * i;
-        sx[i] = e < xe ? Xg[(long)g * xe + e] : 0.f;
+        sx[i] = Xg[(long)g * xe + (e < xe ? e : xe - 1)];              // clamped, not predicated
       }
     }
   };
@@ -599,13 +609,11 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     __bf16* xt = XT + (long)buf * 2 * 32 * WD_XP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int e = tid + WS_NT * i;
-      if (W0 && e < xe) {
-        const int rr = e / p.x_pitch, c = e - rr * p.x_pitch;
-        const float x = (c == p.in0) ? 1.0f : sx[i];
+      if (W0) {
+        const float x = (xo[i] >> 16) ? 1.0f : sx[i];
         const __bf16 hh = (__bf16)x;
-        xt[c * WD_XP + rr] = hh;
-        xt[32 * WD_XP + c * WD_XP + rr] = (__bf16)(x - (float)hh);
+        xt[xo[i] & 0xFFFF] = hh;
+        xt[32 * WD_XP + (xo[i] & 0xFFFF)] = (__bf16)(x - (float)hh);
       }
     }
   };
@@ -623,8 +631,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     if (g0 + gs < p.groups) load_group(g0 + gs);
   }
   __syncthreads();
-  int it = 0;
-  for (int g = g0; g < p.groups; g += gs, ++it) {
+  // steady = true: groups g + gs and g + 2 gs exist -> the body is one basic block (no conditionals)
+  auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
     // epilogue operands of this group: dq of the lane's 4 rows per 16-row block, and the h0 mask word of those rows
     f32x4 dq4[WS_SUB];
@@ -685,10 +693,13 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
         }
       }
     }
-    if (g + gs < p.groups) store_group(buf ^ 1);
-    if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
+    if (steady || g + gs < p.groups) store_group(buf ^ 1);
+    if (steady || g + 2 * gs < p.groups) load_group(g + 2 * gs);
     __syncthreads();
-  }
+  };
+  int g = g0, it = 0;
+  // (a conditional-free steady-state copy of the body, as in ws_fwd / ws_wgrad, measured 4 % slower here: 688 vs 658 us)
+  for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
   if (!W0) return;
   // one slab per workgroup: lane (li, lq) holds dW0^T[c = 16 cbk + 4 lq + r][n = ncol0 + 16 cb + li]
   float* wo = p.w0_out + z0 * p.o_s0 + z1 * p.o_s1 + (long)blockIdx.x * p.o_ks;
@@ -881,10 +892,11 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     if (g0 + gs < p.groups) load_group(g0 + gs);
   }
   __syncthreads();
-  int it = 0;
-  for (int g = g0; g < p.groups; g += gs, ++it) {
+  // steady = true: groups g + gs and g + 2 gs exist -> no conditionals, the whole body up to the barrier is one basic block
+  // (LDS reads of the next k step are hoisted over the MFMAs of the current one)
+  auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
-    const bool more = g + gs < p.groups, more2 = g + 2 * gs < p.groups;
+    const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
     const __bf16* mi = img + (long)buf * 3 * WW_IMG;
     const __bf16* gh = mi + WW_IMG;
     const __bf16* gl = gh + WW_IMG;
@@ -924,11 +936,13 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
         for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[nb], acc[kb0][nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[nb], acc[kb1][nb], 0, 0, 0);
-        if (!TAILS && kp == wave) {                                  // uniform per wave: this wave's share of db1
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bdl, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bdl, accb[1], 0, 0, 0);
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bdh, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bdh, accb[1], 0, 0, 0);
+        if (!TAILS && kp == 7) {                                     // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
+          const bf16x8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
+          const bf16x8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdl, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdl, accb[1], 0, 0, 0);
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdh, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdh, accb[1], 0, 0, 0);
         }
         // each staging register is written to LDS and refilled at the same point of every iteration: a full iteration in flight
         if (kp < 4) {
@@ -942,7 +956,10 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       }
     }
     __syncthreads();
-  }
+  };
+  int g = g0, it = 0;
+  for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
+  for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
 
   // ---- one slab per workgroup ----
   const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
