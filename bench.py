@@ -155,7 +155,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--runs-per-gpu", type=int, default=int(os.environ.get("ORL_RUNS_PER_GPU", "128")),
+    ap.add_argument("--runs-per-gpu", type=int, default=int(os.environ.get("ORL_RUNS_PER_GPU", "96")),
                     help="independent CQL runs (seeds) carried by one engine / GPU; every launch updates all of them")
     ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split-bf16 MFMA (parity-gated)")
     ap.add_argument("--no-single", action="store_true", help="skip the side measurement with ONE run per GPU")

@@ -135,14 +135,14 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
         eng.close()
 
 
-def test_cql_bench_sized_engine_follows_the_oracle():
-    """128 full-size runs per engine in split-bf16 precision (bench.py's default engine): 256 batched critics -> one workgroup per
-    critic in the weight-stationary kernels, top hidden activation not stored, tail gradients derived in the wgrad.  Identical
+@pytest.mark.parametrize("R", [96, 128])
+def test_cql_bench_sized_engine_follows_the_oracle(R):
+    """96 (bench.py's default engine) / 128 full-size runs per engine in split-bf16 precision: 192 / 256 batched critics -> one workgroup
+    per critic in the weight-stationary kernels, top hidden activation not stored, tail gradients derived in the wgrad.  Identical
     inputs for all runs; first, middle and last run must follow the oracle over three steps (the later steps see the updated
     parameters, i.e. the gradients of the earlier ones)."""
     from oracle import cql as ocql
     case = "cql_halfcheetah"
-    R = 128
     eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
     try:
         keys = eng.metric_names
