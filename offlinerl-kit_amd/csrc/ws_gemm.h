@@ -530,7 +530,9 @@ struct WsDgradP {
   int M, nz1, groups;
 };
 enum { WD_XP = WS_ROWS + 4 };                                       // bf16 pitch of an X^T row (72 B: scattered 2-byte stores and 8-byte reads spread over the banks)
-static constexpr size_t ws_dgrad_lds_bytes() { return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WD_XP * 2; }
+static constexpr size_t ws_dgrad_lds_bytes() {     // mask images + X^T images + per-group epilogue operands (dq, h0 mask words)
+  return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
+}
 
 template <bool W0, bool STORE>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
@@ -538,6 +540,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
   __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
+  float* EO = (float*)(XT + 2 * 2 * 32 * WD_XP);                   // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]: epilogue operands
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -583,8 +586,14 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     if (e >= xe) { rr = 32; c = 0; }
     xo[i] = ((c == p.in0) ? (1 << 16) : 0) | (c * WD_XP + rr);        // bit 16: the ones column (bias gradient)
   }
+  float sdq;
+  unsigned int sxw;
   auto load_group = [&](int g) __attribute__((always_inline)) {
     sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    // the epilogue's dq and h0 mask words travel through LDS with the group (fetched a full iteration ahead by the staging threads:
+    // the epilogue then has no global loads of its own to wait for)
+    sdq = dqg[(long)(g * WS_ROWS + (tid & 31)) * p.dq_sm];
+    sxw = xb[(long)(g * WS_ROWS + ((tid >> 3) & 31)) * p.xb_g + (tid & 7)];
     if (W0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -606,6 +615,9 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     __bf16* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
+    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
+    eo[tid & 31] = sdq;                                              // (replicated writes of identical values)
+    ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
     __bf16* xt = XT + (long)buf * 2 * 32 * WD_XP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -637,11 +649,13 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     // epilogue operands of this group: dq of the lane's 4 rows per 16-row block, and the h0 mask word of those rows
     f32x4 dq4[WS_SUB];
     unsigned int xw[WS_SUB][4];
+    const float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      const int m = g * WS_ROWS + 16 * s + 4 * lq;
+      dq4[s] = *(const f32x4*)&eo[16 * s + 4 * lq];
+      const u32x4 w4 = *(const u32x4*)&((const unsigned int*)eo)[WS_ROWS + wave * WS_ROWS + 16 * s + 4 * lq];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { dq4[s][r] = dqg[(long)(m + r) * p.dq_sm]; xw[s][r] = xb[(long)(m + r) * p.xb_g + wave]; }
+      for (int r = 0; r < 4; ++r) xw[s][r] = w4[r];
     }
     const __bf16* ah = Ah + (long)buf * WS_ROWS * WS_PITCH;
     f32x4 acc[WS_SUB][2];
