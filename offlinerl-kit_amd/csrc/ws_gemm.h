@@ -20,6 +20,7 @@
 // crossover of the HBM and matrix-pipe rooflines instead of far below both.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "gemm.h"
@@ -448,6 +449,13 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 }
 
 // host: does the launch qualify?  (split-bf16 precision, K = N = 256, 16-byte aligned operands)
+// CUs one weight-stationary launch spreads over (one workgroup per CU).  ORL_WS_CUS < 256 leaves room for the launches of other
+// engines' streams to run side by side instead of one after the other.
+static inline int ws_cu_budget() {
+  static const int v = [] { const char* f = getenv("ORL_WS_CUS"); const int x = f ? atoi(f) : 0; return (x >= 8 && x <= 256) ? x : 256; }();
+  return v;
+}
+
 static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || (!p.mb && !p.dmask)) return false;
   if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
@@ -469,7 +477,7 @@ static inline hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
   // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems, never more workgroups than CUs
   // (a second partial round of workgroups would double the launch time)
-  int per_z = 256 / nz;
+  int per_z = ws_cu_budget() / nz;
   if (per_z < 1) per_z = 1;
   if (per_z > p.groups) per_z = p.groups;
   const bool l0 = p.X0 != nullptr;
@@ -741,7 +749,7 @@ static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
 // blocks per problem (= split-K slabs written per problem)
 static inline int ws_dgrad_blocks(int M, int nz, int max_slab) {
   const int groups = M / WS_ROWS;
-  int per_z = 256 / nz;
+  int per_z = ws_cu_budget() / nz;
   if (per_z > groups) per_z = groups;
   if (per_z > max_slab) per_z = max_slab;
   return per_z < 1 ? 1 : per_z;
