@@ -10,7 +10,6 @@
 #include "../../include/orl_engine.h"
 #include "gemm.h"
 #include "kernels.h"
-#include "mlp_fused.h"
 #include "ws_gemm.h"
 
 namespace orl {
@@ -144,7 +143,6 @@ struct Engine {
   bool use_graph = true;
   bool force_scalar = false;   // debug: disable the vector loaders
   int loss_nblk = 1;
-  bool use_fused = false;      // fused multi-layer forward kernel (csrc/mlp_fused.h), opt-in with ORL_FUSED=1
   bool elide_top = true;       // many-row single-output nets: keep the top hidden activation out of HBM (ORL_WS_KEEP_H1=1 stores it)
   long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)

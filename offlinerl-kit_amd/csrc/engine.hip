@@ -286,7 +286,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
-  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && !use_fused && in_row0 == 0 && in_rows == in &&
+  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && in_row0 == 0 && in_rows == in &&
       Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
@@ -655,29 +655,6 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   const NetLayout& l = *nr.lay;
   const int Ln = l.L;
   std::string t = tag;
-  // fused path: all hidden layers + tail in one launch (csrc/mlp_fused.h)
-  bool elig = use_fused && !force_scalar && !l.ens && l.out_dim <= 16 && X.pitch >= ((l.in_dim + 3) & ~3) && aligned16(X.p) &&
-              (X.rs & 3) == 0 && (X.cs & 3) == 0 && (X.pitch & 3) == 0;
-  for (int i = 0; i < Ln && elig; ++i) elig = (l.H[i] == 256) && aligned16(hs[i].p) && (hs[i].pitch & 3) == 0 && (hs[i].rs & 3) == 0 && (hs[i].cs & 3) == 0;
-  if (elig) {
-    FusedFwdP p;
-    memset(&p, 0, sizeof(p));
-    p.X = {X.p, X.rs, X.cs}; p.x_sr = X.pitch; p.in_dim = l.in_dim; p.in_pad = (l.in_dim + 3) & ~3;
-    p.M = M; p.L = Ln; p.H = 256; p.out_dim = l.out_dim;
-    p.Wt = {nr.base, nr.rs, l.w_ms[0]};
-    double flops = 0;
-    for (int i = 0; i <= Ln; ++i) { p.w_off[i] = l.w_off[i]; p.b_off[i] = l.b_off[i]; flops += 2.0 * M * l.layer_in(i) * l.layer_out(i); }
-    for (int i = 0; i < Ln; ++i) { p.hs[i] = hs[i].p; p.h_s0[i] = hs[i].rs; p.h_s1[i] = hs[i].cs; p.h_pitch[i] = hs[i].pitch; }
-    p.out = out.p; p.o_s0 = out.rs; p.o_s1 = out.cs; p.o_pitch = out.pitch;
-    p.nz1 = nr.nz1;
-    const int nz = R * nr.nz1;
-    prof_begin((t + ".fused_fwd").c_str(), flops * nz);
-    hipError_t err = launch_fused_fwd(p, nz, cfg.precision, stream);
-    prof_end();
-    if (err == hipSuccess) return 0;
-    if (err != hipErrorNotSupported) return fail(std::string("fused forward launch ") + tag + ": " + hipGetErrorString(err));
-    if (prof_on) prof.pop_back();
-  }
   bool tail_done = false;
   for (int i = 0; i < Ln; ++i) {
     if (i == 0 && Ln >= 2) continue;         // layer 0 is issued together with layer 1 (fused into it when the ws kernel applies)
@@ -829,10 +806,9 @@ int Engine::init(const orl_config& c) {
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
-  { const char* f = getenv("ORL_FUSED"); use_fused = f && atoi(f) != 0; }
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
-  { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }   // opt-in: measured slower than the layer-wise kernels
+  { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {

@@ -1,0 +1,388 @@
+// ws_fwd.hip — weight-stationary forward of the 256-wide layers (+ fused first layer, tail, mask bits; plain-dgrad mode) (interface and design notes: ws_gemm.h).
+#include "ws_device.h"
+
+namespace orl {
+
+template <bool TQ, bool L0, bool DG = false, bool SY = true>      // SY = false: the activation itself is not stored (TQ only)
+__global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
+  float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
+  unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
+  float* Xl = (float*)(nbs + 2 * WS_ROWS * WS_NBP);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
+  unsigned char* nbs0 = (unsigned char*)(Xl + 2 * WS_ROWS * WS_XLP);         // L0: mask nibbles of the produced h0
+  float* cst = (float*)((char*)ws_smem + ws_fwd_lds_bytes(L0) - sizeof(float) * 2 * WS_N);   // [bias | tail weights]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
+  const float* __restrict__ bg = DG ? nullptr : p.bias + z0 * p.b_s0 + z1 * p.b_s1;
+  float* __restrict__ Yg = p.Y + z0 * p.y_s0 + z1 * p.y_s1;
+  const int ncol0 = 16 * WS_CB * wave;
+  float* __restrict__ Y0g = L0 ? const_cast<float*>(Xg) : nullptr;       // L0: h0 is written where the plain kernel reads it
+  const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
+
+  // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
+  bf16x8 bh[WS_CB][8], bl[WS_CB][8];
+#pragma unroll
+  for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
+      if (p.w_sk == 1) ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
+      else {                                           // (in, out)-major weights: eight strided loads, once per workgroup
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = src[(long)j * p.w_sk]; b[j] = src[(long)(4 + j) * p.w_sk]; }
+        ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
+      }
+    }
+  // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
+  bf16x8 b0h[WS_CB], b0l[WS_CB];
+  if (L0) {
+    const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
+    const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
+#pragma unroll
+    for (int cb = 0; cb < WS_CB; ++cb) {
+      const int n = ncol0 + 16 * cb + li;
+      f32x4 a, b;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k0 = 8 * lq + j, k1 = k0 + 4;
+        a[j] = k0 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k0 * p.w0_sk] : (k0 == p.in0 ? b0g[n] : 0.f);
+        b[j] = k1 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k1 * p.w0_sk] : (k1 == p.in0 ? b0g[n] : 0.f);
+      }
+      ws_split8(a, b, b0h[cb], b0l[cb]);
+    }
+  }
+  // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r sit in LDS (not in 16 VGPRs next to the 128 VGPRs of
+  // resident B fragments, and not re-read from global memory: vmcnt is in-order, so waiting for such a load in the epilogue would
+  // also wait for every activation store issued before it)
+  const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
+  if (!DG && tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }      // visible after the prologue's barriers
+  const float tbias = TQ ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
+
+  // ---- staging of one row group: thread t moves float4 #(t + 512 i), i = 0..7, of the [64][256] tile ----
+  // one staging register set: refilled with group g + 2 gs right after group g + gs has been written to LDS
+  f32x4 st0[WS_LD];
+  auto load_group = [&](int g, f32x4 (&st)[WS_LD]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < WS_LD; ++i) {
+      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      int m = g * WS_ROWS + r; m = m < p.M ? m : p.M - 1;
+      st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
+    }
+  };
+  auto load_piece = [&](int g, f32x4 (&st)[WS_LD], int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    int m = g * WS_ROWS + r; m = m < p.M ? m : p.M - 1;
+    st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
+  };
+  auto store_group = [&](int buf, const f32x4 (&st)[WS_LD], int i0 = 0, int i1 = WS_LD) __attribute__((always_inline)) {
+    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      bf16x4 h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)st[i][j]; h[j] = hh; l[j] = (__bf16)(st[i][j] - (float)hh); }
+      // 16-byte chunk c = k / 8 of row r lives at chunk c ^ (r & 15): ds_read_b128 of a fragment column is then conflict-free
+      // for the hardware's 16-lane groups (which mix lanes of two neighbouring chunks), and these 8-byte stores stay so too
+      const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
+      *(bf16x4*)(dh + o) = h;
+      *(bf16x4*)(dl + o) = l;
+    }
+  };
+
+  // ---- L0: narrow-input staging (two elements per thread) and the producer of one h0 row group ----
+  const int xe = L0 ? WS_ROWS * p.x0_pitch : 0;
+  int xr[2], xc[2];
+  float sx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0;
+    if (L0 && e >= xe) { xr[i] = 0; xc[i] = 32; }       // never read (rows are consumed as 32 columns of the 36-float pitch)
+  }
+  auto loadX = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
+  };
+  auto storeX = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];   // surplus threads: pad column 32
+  };
+  // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
+  auto prod_x = [&](int xbuf, int s, bf16x8& xah, bf16x8& xal) __attribute__((always_inline)) {
+    const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 8 * lq;
+    ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+  };
+  auto prod_block = [&](int g, int buf, int par, int s, int cb, const bf16x8& xah, const bf16x8& xal) __attribute__((always_inline)) {
+    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+    const int r = 16 * s + li;
+    const long m = (long)g * WS_ROWS + r;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
+    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
+    *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)v[j]; h[j] = hh; l[j] = (__bf16)(v[j] - (float)hh); }
+    const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
+    *(bf16x4*)(dh + o) = h;
+    *(bf16x4*)(dl + o) = l;
+    nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
+        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+  };
+  auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      bf16x8 xah, xal;
+      prod_x(xbuf, s, xah, xal);
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) prod_block(g, buf, par, s, cb, xah, xal);
+    }
+  };
+  auto finish0 = [&](int g, int par) __attribute__((always_inline)) {  // after the barrier that follows produce(g): pack the h0 mask
+    if (tid < WS_ROWS * 8) {
+      const int row = tid >> 3, wd = tid & 7;
+      const unsigned int* nb = (const unsigned int*)(nbs0 + (par * WS_ROWS + row) * WS_NBP + 8 * wd);
+      const unsigned int d0 = nb[0], d1 = nb[1];
+      const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
+      const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
+      p.mb0[z0 * p.mb0_s0 + z1 * p.mb0_s1 + ((long)g * WS_ROWS + row) * p.mb0_g + wd] = lo16 | (hi16 << 16);
+    }
+  };
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 >= p.groups) return;
+  if (L0) {
+    for (int e = tid; e < 2 * WS_ROWS * WS_XLP; e += WS_NT) Xl[e] = 0.f;   // columns >= x0_pitch stay zero
+    loadX(g0);
+    __syncthreads();
+    storeX(0);
+    if (g0 + gs < p.groups) loadX(g0 + gs);
+    __syncthreads();
+    produce(g0, 0, 0, 0);
+    if (g0 + gs < p.groups) storeX(1);
+    if (g0 + 2 * gs < p.groups) loadX(g0 + 2 * gs);
+    __syncthreads();
+    finish0(g0, 0);
+  } else {
+    load_group(g0, st0);
+    store_group(0, st0);
+    if (g0 + gs < p.groups) load_group(g0 + gs, st0);
+    __syncthreads();
+  }
+  // Software pipeline: iteration `it` multiplies group g out of LDS buffer it & 1 while the epilogue of the PREVIOUS group
+  // (accumulators `pacc`) runs in the shadow of those MFMAs -- both are in one basic block (no row guards: M is a multiple of
+  // WS_ROWS), so the scheduler can pair every MFMA with the VALU / store work of the other stage.  Then group g + gs is staged
+  // from register set (it + 1) & 1.
+  constexpr bool storeY = SY;                      // false: a single-output net whose backward needs only the mask bits of this activation
+  // one 16 x 16 block of the (non-gradient) epilogue: bias, ReLU, optional store, tail partial sum, 4 mask bits -> LDS
+  auto epi_block = [&](const f32x4& a, int g, int par, int s, int cb, float& part) __attribute__((always_inline)) {
+    const f32x4 bq = *(const f32x4*)&cst[ncol0 + 16 * cb + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol0 + 16 * cb + 4 * lq];
+    const int m = g * WS_ROWS + 16 * s + li;
+    f32x4 v = a + bq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+    part += (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
+    // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
+    nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
+        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+  };
+  auto epi_row = [&](int par, int s, float part) __attribute__((always_inline)) {
+    if (TQ) {
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      (qs + (par * WS_NW + wave) * WS_ROWS)[16 * s + li] = part;   // all four lq lanes hold the same sum: no divergent branch in this block
+    }
+  };
+  auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
+    if (DG) {                                      // gradient epilogue: ReLU mask of the receiving activation from its packed bits
+      static_assert(!DG || WS_CB == 2, "one 32-column mask word per wave");
+      const unsigned int* __restrict__ dm = p.dmask + z0 * p.dm_s0 + z1 * p.dm_s1;
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const long m = (long)g * WS_ROWS + 16 * s + li;
+        const unsigned int w = dm[m * p.dm_g + wave];
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) {
+          const unsigned int nib = w >> (16 * cb + 4 * lq);
+          f32x4 v = acc[s][cb];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] : 0.f;
+          *(f32x4*)&Yg[m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      float part = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) epi_block(acc[s][cb], g, par, s, cb, part);
+      epi_row(par, s, part);
+    }
+  };
+  auto finish = [&](int g, int par) __attribute__((always_inline)) {   // after the barrier that follows epilogue(g)
+    if (DG) return;
+    if (tid < WS_ROWS * 8) {                         // thread (row, word): eight nibbles -> one 32-column mask word
+      const int row = tid >> 3, wd = tid & 7, m = g * WS_ROWS + row;
+      const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * WS_NBP + 8 * wd);
+      const unsigned int d0 = nb[0], d1 = nb[1];
+      const unsigned int lo16 = (d0 & 0xFu) | ((d0 >> 4) & 0xF0u) | ((d0 >> 8) & 0xF00u) | ((d0 >> 12) & 0xF000u);
+      const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
+      p.mb[z0 * p.mb_s0 + z1 * p.mb_s1 + (long)m * p.mb_g + wd] = lo16 | (hi16 << 16);
+    }
+    if (TQ && tid < WS_ROWS) {                       // eight column-slice partial sums per row, fixed order
+      const int m = g * WS_ROWS + tid;
+      const float* q8 = qs + par * WS_NW * WS_ROWS + tid;
+      float a = tbias;
+#pragma unroll
+      for (int w = 0; w < WS_NW; ++w) a += q8[w * WS_ROWS];
+      p.tq[z0 * p.tq_s0 + z1 * p.tq_s1 + (long)m * p.tq_sm] = a;
+    }
+  };
+
+  f32x4 pacc[WS_SUB][WS_CB];
+  // steady = true: groups g + gs .. g + 3 gs exist, so the body has no conditionals (one basic block up to the barrier)
+  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady) __attribute__((always_inline)) {
+    const int buf = it & 1;
+    const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    const __bf16* al = ah + WS_ROWS * WS_PITCH;
+    f32x4 acc[WS_SUB][WS_CB];
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool fine = steady && !DG;
+    float fpart = 0.f;
+    bf16x8 fxah, fxal;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      // the three products of a block are issued plane by plane (lo*hi, hi*lo, hi*hi over all four blocks) so that dependent MFMAs
+      // on one accumulator are four instructions apart; operands swapped: D[n][m], lane holds C[m = li][n = 4 lq + r]
+      bf16x8 fah2[WS_SUB], fal2[WS_SUB];
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        const int o = (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3);
+        fah2[s] = *(const bf16x8*)&ah[o]; fal2[s] = *(const bf16x8*)&al[o];
+      }
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fal2[s], acc[s][cb], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+      if (fine) {
+        // Steady state: the work of the other pipeline stages is cut into eight pieces, one per k step, and fenced together
+        // with that step's 12 MFMAs -- the default scheduler otherwise clusters all 96 MFMAs and the matrix pipe idles during
+        // the epilogue / staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue;
+        // 4..7: the four blocks of the next group's first layer (or the four staging pieces of the plain variant).
+        static_assert(WS_SUB == 2 && WS_CB == 2 && WS_LD == 4, "eight pieces");
+        const int par = (it - 1) & 1;
+        if (ks < 4) {
+          const int s = ks >> 1, cb = ks & 1;
+          if (cb == 0) fpart = 0.f;
+          epi_block(pacc[s][cb], g - gs, par, s, cb, fpart);
+          if (cb == 1) epi_row(par, s, fpart);
+        } else if (L0) {
+          const int s = (ks - 4) >> 1, cb = (ks - 4) & 1;
+          if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxal);
+          prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxal);
+        } else {
+          store_group(buf ^ 1, stn, ks - 4, ks - 3);
+          load_piece(g + 2 * gs, stn, ks - 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (fine) {
+      if (L0) { storeX(it & 1); loadX(g + 3 * gs); }
+    } else {
+      if (!first) epilogue(pacc, g - gs, (it - 1) & 1);
+      if (L0) {
+        // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
+        if (steady || g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
+        if (steady || g + 2 * gs < p.groups) storeX(it & 1);
+        if (steady || g + 3 * gs < p.groups) loadX(g + 3 * gs);
+      } else {
+        if (steady || g + gs < p.groups) store_group(buf ^ 1, stn);
+        if (steady || g + 2 * gs < p.groups) load_group(g + 2 * gs, stn);
+      }
+    }
+    __syncthreads();
+    if (!first) finish(g - gs, (it - 1) & 1);
+    if (L0 && (steady || g + gs < p.groups)) finish0(g + gs, (it + 1) & 1);
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb) pacc[s][cb] = acc[s][cb];
+  };
+  int g = g0, it = 0;
+  iteration(g, it, st0, true, false);
+  g += gs; ++it;
+  while (g + 3 * gs < p.groups) {
+    iteration(g, it, st0, false, true);
+    g += gs; ++it;
+  }
+  while (g < p.groups) {
+    iteration(g, it, st0, false, false);
+    g += gs; ++it;
+  }
+  // drain: the last group's epilogue
+  epilogue(pacc, g - gs, (it - 1) & 1);
+  __syncthreads();
+  finish(g - gs, (it - 1) & 1);
+}
+
+hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
+  p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
+  // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems, never more workgroups than CUs
+  // (a second partial round of workgroups would double the launch time)
+  int per_z = ws_cu_budget() / nz;
+  if (per_z < 1) per_z = 1;
+  if (per_z > p.groups) per_z = p.groups;
+  const bool l0 = p.X0 != nullptr;
+  const size_t lds = ws_fwd_lds_bytes(l0);
+  static const hipError_t attr_err = [] {       // thread-safe one-time initialisation (engines may launch from several host threads)
+    const int big = (int)ws_fwd_lds_bytes(true);
+    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
+  const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true>), grid, block, lds, st, p);
+  else if (l0) {
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, true>), grid, block, lds, st, p);
+  } else {
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, false, false, false>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, false>), grid, block, lds, st, p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace orl

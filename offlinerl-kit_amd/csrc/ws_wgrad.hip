@@ -1,0 +1,288 @@
+// ws_wgrad.hip — output-stationary top-layer weight gradient (+ tail-layer gradients) (interface and design notes: ws_gemm.h).
+#include "ws_device.h"
+
+namespace orl {
+
+// bf16 offset of the 8-byte piece (16-byte chunk `chunk`, half `half`) of row r: chunks are XOR-swizzled with 2 (r & 7) so that
+// the transposed reads (8 rows x 32 B per 32-lane half) and the 8-byte staging stores are both bank-conflict free
+__device__ inline int ww_off(int r, int chunk, int half) { return r * WS_K + ((chunk ^ (2 * (r & 7))) << 3) + (half << 2); }
+
+__device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
+  // 16-lane group lq reads rows row0 + 4 lq + q (q = li >> 2), columns col0 + 4 (li & 3) ..; lane li receives column col0 + li of
+  // rows row0 + 4 lq .. + 3  (= the 16x16x16 MFMA operand layout, for A as the transpose of the image)
+  const int li = lane & 15, lq = lane >> 4, row = row0 + 4 * lq + (li >> 2), col = col0 + 4 * (li & 3);
+  const __bf16* a = img + ww_off(row, col >> 3, (col >> 2) & 1);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
+}
+
+template <int MODE>      // 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators
+__global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
+  static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
+  constexpr bool TAILS = (MODE == 1);
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  __bf16* img = (__bf16*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ H0g = p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1;
+  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const int ncol0 = 32 * wave;
+
+  f32x4 acc[16][2], accb[2];
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) acc[kb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- staging registers of one row group ----
+  f32x4 s0[4];
+  f32x4 s1[TAILS ? 4 : 1];
+  f32x4 tacc = (f32x4){0.f, 0.f, 0.f, 0.f}, bacc = (f32x4){0.f, 0.f, 0.f, 0.f};   // TAILS: dw_tail / db1 partials of columns 4 (tid & 63) ..
+  float dqsum = 0.f;
+  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
+  float sdq[4];
+  unsigned int sm_word;
+  __bf16* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
+  auto load_group = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      const long m = (long)g * WS_ROWS + r;
+      s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+      if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
+      sdq[i] = dqg[m * p.dq_sm];
+    }
+  };
+  auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    const long m = (long)g * WS_ROWS + r;
+    s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+    if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
+    sdq[i] = dqg[m * p.dq_sm];
+  };
+  auto load_mask = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+  };
+  auto store_mask = [&](int buf) __attribute__((always_inline)) {
+    __bf16* mi = img + (long)buf * 3 * WW_IMG;
+    const int r = tid >> 4, hw = tid & 15;
+    const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
+    u32x4 c0, c1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int y0 = (bits >> (2 * j)) & 3u, y1 = (bits >> (8 + 2 * j)) & 3u;
+      c0[j] = ((y0 & 1u) | ((y0 >> 1) << 16)) * 0x3F80u;
+      c1[j] = ((y1 & 1u) | ((y1 >> 1) << 16)) * 0x3F80u;
+    }
+    *(u32x4*)(mi + ww_off(r, 2 * hw, 0)) = c0;
+    *(u32x4*)(mi + ww_off(r, 2 * hw + 1, 0)) = c1;
+  };
+  auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
+    __bf16* gh = img + (long)buf * 3 * WW_IMG + WW_IMG;
+    __bf16* gl = gh + WW_IMG;
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gv = s0[i][j] * sdq[i];
+      const __bf16 hh = (__bf16)gv; h[j] = hh; l[j] = (__bf16)(gv - (float)hh);
+    }
+    const int o = ww_off(r, kq >> 1, kq & 1);
+    *(bf16x4*)(gh + o) = h;
+    *(bf16x4*)(gl + o) = l;
+    if (TAILS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { tacc[j] += sdq[i] * s1[i][j]; bacc[j] += s1[i][j] > 0.f ? sdq[i] : 0.f; }
+      dqsum += sdq[i];
+    } else if (kq == 0) {                                            // this row's dq into the bias-gradient operand block
+      const __bf16 hh = (__bf16)sdq[i];
+      __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
+      dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = (__bf16)(sdq[i] - (float)hh);
+      if (MODE == 2) dqsum += sdq[i];
+    }
+  };
+  auto store_group = [&](int buf) __attribute__((always_inline)) {
+    store_mask(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(buf, i);
+  };
+  if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
+  __syncthreads();
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 < p.groups) {
+    load_group(g0);
+    store_group(0);
+    if (g0 + gs < p.groups) load_group(g0 + gs);
+  }
+  __syncthreads();
+  // steady = true: groups g + gs and g + 2 gs exist -> no conditionals, the whole body up to the barrier is one basic block
+  // (LDS reads of the next k step are hoisted over the MFMAs of the current one)
+  auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
+    const int buf = it & 1;
+    const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
+    const __bf16* mi = img + (long)buf * 3 * WW_IMG;
+    const __bf16* gh = mi + WW_IMG;
+    const __bf16* gl = gh + WW_IMG;
+    const __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
+    {
+      // one v_mfma_f32_16x16x32_bf16 covers the whole 32-row group: its 8 k-values per lane are the two transposed reads of
+      // rows 4 lq .. + 3 and 16 + 4 lq .. + 3 (the k order is free as long as A and B agree)
+      auto cat = [](s16x4 x, s16x4 y) __attribute__((always_inline)) {
+        bf16x8 r;
+        *(s16x4*)&r = x; *((s16x4*)&r + 1) = y;
+        return r;
+      };
+      bf16x8 bh[2], bl[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        bh[nb] = cat(ww_tr(gh, 0, ncol0 + 16 * nb, lane), ww_tr(gh, 16, ncol0 + 16 * nb, lane));
+        bl[nb] = cat(ww_tr(gl, 0, ncol0 + 16 * nb, lane), ww_tr(gl, 16, ncol0 + 16 * nb, lane));
+      }
+      const int dro0 = (4 * lq + (li >> 2)) * 16 + 4 * (li & 3), dro1 = dro0 + 16 * 16;
+      typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+      bf16x8 bdh, bdl;
+      if (!TAILS) {
+        bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
+        bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
+                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
+      }
+#pragma unroll
+      for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
+        const int kb0 = 2 * kp, kb1 = kb0 + 1;
+        const bf16x8 a0 = cat(ww_tr(mi, 0, 16 * kb0, lane), ww_tr(mi, 16, 16 * kb0, lane));   // A[i = k][kk = m] = mask[m][k]
+        const bf16x8 a1 = cat(ww_tr(mi, 0, 16 * kb1, lane), ww_tr(mi, 16, 16 * kb1, lane));
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bl[nb], acc[kb0][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bl[nb], acc[kb1][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[nb], acc[kb0][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[nb], acc[kb1][nb], 0, 0, 0);
+        if (!TAILS && kp == 7) {                                     // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
+          const bf16x8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
+          const bf16x8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdl, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdl, accb[1], 0, 0, 0);
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdh, accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdh, accb[1], 0, 0, 0);
+        }
+        // each staging register is written to LDS and refilled at the same point of every iteration: a full iteration in flight
+        if (kp < 4) {
+          if (more) store_piece(buf ^ 1, kp);
+          if (more2) load_piece(g + 2 * gs, kp);
+        }
+        if (kp == 5) {
+          if (more) store_mask(buf ^ 1);
+          if (more2) load_mask(g + 2 * gs);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  int g = g0, it = 0;
+  for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
+  for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
+
+  // ---- one slab per workgroup ----
+  const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
+  float* dW = p.dW + so + z1 * p.o_s1w;
+  float* db = p.db + so + z1 * p.o_s1b;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    const f32x4 w4 = *(const f32x4*)&wtg[16 * kb + 4 * lq];           // lane holds rows k = 16 kb + 4 lq + r, column n = ncol0 + 16 nb + li
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
+  }
+  if (MODE == 2) {
+    // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
+    // group and then the 8 waves (= all 256 input columns) are summed in a fixed order
+    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
+    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * kb + 4 * lq + r;
+        float t = W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        if (li == 0) red[wave * WS_K + o] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r];
+    }
+    if (lane == 0) red[9 * WS_K + wave] = dqsum;
+    __syncthreads();
+    if (tid < WS_K) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[w * WS_K + tid];
+      const float gs1 = red[8 * WS_K + tid];
+      p.dwt[so + z1 * p.o_s1wt + tid] = a + (p.b1 + z0 * p.b1_s0 + z1 * p.b1_s1)[tid] * gs1;
+      db[tid] = wtg[tid] * gs1;
+    }
+    if (tid == 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[9 * WS_K + w];
+      p.dbt[so + z1 * p.o_s1bt] = a;
+    }
+    return;
+  }
+  if (!TAILS) {
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int k0 = 16 * (2 * wave + x) + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
+      }
+    }
+    return;
+  }
+  // TAILS: eight row-slice partial sums per column (threads tid, tid + 64, ...), summed in a fixed order
+  float* red = ws_smem;                                              // the images are dead after the loop's last barrier
+  *(f32x4*)&red[(tid >> 6) * WS_K + 4 * (tid & 63)] = tacc;
+  *(f32x4*)&red[(8 + (tid >> 6)) * WS_K + 4 * (tid & 63)] = bacc;
+  if ((tid & 63) == 0) red[16 * WS_K + (tid >> 6)] = dqsum;
+  __syncthreads();
+  if (tid < WS_K) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += red[w * WS_K + tid]; b += red[(8 + w) * WS_K + tid]; }
+    p.dwt[so + z1 * p.o_s1wt + tid] = a;
+    db[tid] = wtg[tid] * b;
+  }
+  if (tid == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[16 * WS_K + w];
+    p.dbt[so + z1 * p.o_s1bt] = a;
+  }
+}
+
+hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
+  p.groups = p.M / WS_ROWS;
+  static const hipError_t attr_err = [] {
+    hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
+  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<1>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  else if (p.W1) hipLaunchKernelGGL(ws_wgrad_kernel<2>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_wgrad_kernel<0>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  return hipGetLastError();
+}
+
+}  // namespace orl

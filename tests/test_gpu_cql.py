@@ -268,20 +268,3 @@ def test_cql_split_bf16_precision_meets_the_gate(case):
                     assert scale_err(eng.debug_read(0, tap), g[gkey]) < 1e-4, (tap, scale_err(eng.debug_read(0, tap), g[gkey]))
     print(case, "worst loss rel err (split-bf16):", worst)
     eng.close()
-
-
-@pytest.mark.parametrize("precision", [0, 1])
-def test_cql_opt_in_fused_forward_kernel(precision, monkeypatch):
-    """ORL_FUSED=1 routes every eligible MLP forward through csrc/mlp_fused.h (kept opt-in: measured slower than
-    the layer-wise kernels); it must meet the same parity gate."""
-    monkeypatch.setenv("ORL_FUSED", "1")
-    case = "cql_halfcheetah"
-    eng, cfg, st, batches, noises = make_engine(case, precision=precision)
-    g = load_golden(case)
-    for k, (b, n) in enumerate(zip(batches[:5], noises[:5])):
-        m = eng.step(lead(b), lead(noise_list(n)))[0]
-        assert rel_err(m, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (k, m, g[f"step{k}/losses"])
-        if k == 0:
-            assert scale_err(eng.debug_read(0, "q1"), g["step0/c1_q"]) < 1e-4
-            assert scale_err(eng.debug_read(0, "q1a"), g["step0/c1_qa"]) < 1e-4
-    eng.close()
