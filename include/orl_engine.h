@@ -55,6 +55,13 @@ extern "C" {
 #define ORL_SCALAR_LOG_ALPHA 0
 #define ORL_SCALAR_CQL_LOG_ALPHA 1
 #define ORL_SCALAR_ALPHA 2 /* read-only: the alpha the next learn() will use */
+/* optimizer state of the scalars (torch.optim.Adam exp_avg / exp_avg_sq of alpha_optim, cql_alpha_optim) and TD3's
+ * _last_actor_loss (td3.py:59): readable / writable so a policy can be re-bound or checkpointed without losing them */
+#define ORL_SCALAR_LOG_ALPHA_M 3
+#define ORL_SCALAR_LOG_ALPHA_V 4
+#define ORL_SCALAR_CQL_LOG_ALPHA_M 5
+#define ORL_SCALAR_CQL_LOG_ALPHA_V 6
+#define ORL_SCALAR_LAST_ACTOR_LOSS 7
 
 /* optimizer ids for orl_set_lr (run_iql.py:133 mutates actor_optim's lr per epoch) */
 #define ORL_OPT_ACTOR 0
@@ -146,6 +153,12 @@ int orl_scalar_set(orl_engine* e, int run, int which, float v);
 int orl_scalar_get(orl_engine* e, int run, int which, float* v);
 int orl_set_lr(orl_engine* e, int opt, float lr);       /* optim.param_groups[0]["lr"] = lr */
 int orl_reset_optimizers(orl_engine* e);                /* fresh torch.optim.Adam state (step=0, m=v=0) */
+/* torch.optim.Adam state_dict()["state"] of a trainable net's optimizer: exp_avg / exp_avg_sq flat in state_dict order
+ * (orl_net_floats values each); the shared step count is orl_step_count / orl_set_step_count (every optimizer of a policy steps
+ * once per learn(); TD3BC's actor optimizer steps on every update_actor_freq-th call and derives its own count from it). */
+int orl_adam_get(orl_engine* e, int run, int net, float* exp_avg, float* exp_avg_sq, int64_t n_floats);
+int orl_adam_set(orl_engine* e, int run, int net, const float* exp_avg, const float* exp_avg_sq, int64_t n_floats);
+int orl_set_step_count(orl_engine* e, int64_t steps);   /* resume: Adam's t, TD3BC's _cnt and the device RNG offsets continue from here */
 
 /* -- replay buffer (buffer/buffer.py): its own object, like the reference's ReplayBuffer ------- */
 typedef struct orl_buffer orl_buffer;
@@ -180,8 +193,13 @@ int64_t orl_step_count(orl_engine* e);
 
 /* -- test / profiling taps --------------------------------------------------------- */
 /* copies an intermediate of the LAST step to host: returns number of floats written or <0.
- * names: "q1","q2","target_q","q1a","q2a","logp_a", ... (algorithm specific) */
+ * names: "q1","q2","target_q","q1a","q2a","logp_a", ... (algorithm specific); every engine also has the minibatch of the last
+ * step ("b_obs","b_nobs","b_act","b_rew","b_term": what ReplayBuffer.sample returned / the device sampler drew) and its noise
+ * arrays under their orl_noise slot names ("n_eps_actor", ...). */
 int64_t orl_debug_read(orl_engine* e, int run, const char* name, float* host, int64_t cap);
+/* gradient of the LAST step w.r.t. the parameters of a trainable net, flat in state_dict order (orl_net_floats values): what
+ * autograd leaves in param.grad before optimizer.step() (cql.py:180-190 etc.); the split-K slabs of the backward kernels summed. */
+int orl_debug_grads(orl_engine* e, int run, int net, float* host, int64_t n_floats);
 /* runs one generic GEMM tile configuration on host data (kernel unit tests): see csrc/gemm.h */
 int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* B, const float* v0,
                    const float* v1, float* C, int ksplit, int precision);

@@ -90,6 +90,7 @@ struct Buffer {             // HBM-resident replay buffer (buffer/buffer.py)
   float *obs = nullptr, *nobs = nullptr, *act = nullptr, *rew = nullptr, *term = nullptr;
   long long* idx = nullptr; long idx_cap = 0;
   unsigned long long counter = 0;
+  unsigned long long gen = 0;   // bumped by every orl_buffer_load: engines re-capture graphs that hold the old dataset pointers / size
   ~Buffer();
 };
 
@@ -119,6 +120,10 @@ struct Engine {
   int nm = 0;
   std::vector<std::string> metric_names;
   Buffer* buf = nullptr;       // attached replay buffer (not owned)
+  unsigned long long buf_gen = 0;   // Buffer::gen the captured graphs were built against
+  void drop_graphs();
+  // split-K slab table of the last adam() launch per net (orl_debug_grads sums the slabs the way k_adam does)
+  std::vector<std::pair<long, int>> last_segs[ORL_NUM_NETS];
   std::vector<void*> allocs;
   std::map<std::string, Mat> ws;
   std::map<std::string, long> ws_len;

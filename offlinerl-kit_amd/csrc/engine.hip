@@ -166,6 +166,13 @@ Engine::~Engine() {
   if (stream) hipStreamDestroy(stream);
 }
 
+void Engine::drop_graphs() {
+  for (int i = 0; i < 2; ++i) {
+    if (graph_exec[i]) { hipGraphExecDestroy(graph_exec[i]); graph_exec[i] = nullptr; }
+    if (graph[i]) { hipGraphDestroy(graph[i]); graph[i] = nullptr; }
+  }
+}
+
 float* Engine::raw_alloc(size_t bytes) {
   void* p = nullptr;
   if (bytes == 0) bytes = 16;
@@ -624,6 +631,7 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   a.g = grads + net_off[net]; a.g_s0 = (long)max_slab * P_train; a.g_s1 = l.stride(); a.g_ks = P_train;
   a.nseg = (int)segs.size();
   if (a.nseg > 12) return fail("too many adam segments");
+  for (int i = 0; i < nnets && net + i < ORL_NUM_NETS; ++i) last_segs[net + i] = segs;
   for (int i = 0; i < a.nseg; ++i) { a.seg_end[i] = segs[i].first; a.seg_nslab[i] = segs[i].second; }
   if (target_net >= 0) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.stride(); }
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
@@ -765,6 +773,11 @@ int Engine::build_common() {
   alloc("b_obs2", 2 * B, OP);
   alloc("b_act", B, AP); alloc("b_rew", B, 1); alloc("b_term", B, 1);
   alloc("ones", std::max(B, 16), 1);
+  taps["b_obs"] = {W("b_obs2"), B, od};
+  taps["b_nobs"] = {W("b_obs2").rows(B), B, od};
+  taps["b_act"] = {W("b_act"), B, ad};
+  taps["b_rew"] = {W("b_rew"), B, 1};
+  taps["b_term"] = {W("b_term"), B, 1};
   // column-tile partial sums of fused single-output tails (linear_fwd): up to 3 extra parts of the longest row batch
   tq_scratch_nets = std::max(2, K);
   alloc("tq_scratch", 3L * (B + 3L * B * N), 1, tq_scratch_nets);
@@ -818,6 +831,7 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_EDAC: rc = edac_build(); break;
   }
   if (rc) return rc;
+  for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ad};      // the noise arrays of the last step
   nm = (int)metric_names.size();
   if (nm > ORL_MAX_METRICS) return fail("too many metrics");
   metrics_last = raw_alloc(sizeof(float) * R * nm);
@@ -1015,6 +1029,12 @@ int orl_scalar_set(orl_engine* h, int run, int which, float v) {
   ORL_HIP(hipMemcpy(&s, e.scalars + run, sizeof(s), hipMemcpyDeviceToHost));
   if (which == ORL_SCALAR_LOG_ALPHA) { s.log_alpha = v; if (e.cfg.auto_alpha) s.alpha = expf(v); }   // sac.py:46 / edac.py:45
   else if (which == ORL_SCALAR_CQL_LOG_ALPHA) s.cql_log_alpha = v;
+  else if (which == ORL_SCALAR_ALPHA) s.alpha = v;       // resume: EDAC / SAC keep a clamped alpha between steps (edac.py:110)
+  else if (which == ORL_SCALAR_LOG_ALPHA_M) s.la_m = v;
+  else if (which == ORL_SCALAR_LOG_ALPHA_V) s.la_v = v;
+  else if (which == ORL_SCALAR_CQL_LOG_ALPHA_M) s.cla_m = v;
+  else if (which == ORL_SCALAR_CQL_LOG_ALPHA_V) s.cla_v = v;
+  else if (which == ORL_SCALAR_LAST_ACTOR_LOSS) s.last_actor_loss = v;
   else return fail("scalar not settable");
   ORL_HIP(hipMemcpy(e.scalars + run, &s, sizeof(s), hipMemcpyHostToDevice));
   return 0;
@@ -1028,6 +1048,11 @@ int orl_scalar_get(orl_engine* h, int run, int which, float* v) {
   if (which == ORL_SCALAR_LOG_ALPHA) *v = s.log_alpha;
   else if (which == ORL_SCALAR_CQL_LOG_ALPHA) *v = s.cql_log_alpha;
   else if (which == ORL_SCALAR_ALPHA) *v = e.cfg.auto_alpha ? s.alpha : e.cfg.alpha;
+  else if (which == ORL_SCALAR_LOG_ALPHA_M) *v = s.la_m;
+  else if (which == ORL_SCALAR_LOG_ALPHA_V) *v = s.la_v;
+  else if (which == ORL_SCALAR_CQL_LOG_ALPHA_M) *v = s.cla_m;
+  else if (which == ORL_SCALAR_CQL_LOG_ALPHA_V) *v = s.cla_v;
+  else if (which == ORL_SCALAR_LAST_ACTOR_LOSS) *v = s.last_actor_loss;
   else return fail("unknown scalar");
   return 0;
 }
@@ -1045,6 +1070,36 @@ int orl_reset_optimizers(orl_engine* h) {
   ORL_HIP(hipMemsetAsync(e.gstep, 0, sizeof(unsigned long long), e.stream));
   e.step_host = 0;
   ORL_HIP(hipStreamSynchronize(e.stream));
+  return 0;
+}
+static int adam_xfer(orl_engine* h, int run, int net, float* m, float* v, int64_t n, bool to_host) {
+  Engine& e = h->e;
+  if (run < 0 || run >= e.R || net < 0 || net >= ORL_NUM_NETS || !e.lay[net].present || e.net_is_target[net]) return fail("orl_adam: bad run / net");
+  if (n != e.lay[net].size || !m || !v) return fail("orl_adam: bad size");
+  ORL_HIP(hipSetDevice(e.dev));
+  ORL_HIP(hipStreamSynchronize(e.stream));
+  const long off = (long)run * e.P_train + e.net_off[net];
+  if (to_host) {
+    ORL_HIP(hipMemcpy(m, e.adam_m + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+    ORL_HIP(hipMemcpy(v, e.adam_v + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+  } else {
+    ORL_HIP(hipMemcpy(e.adam_m + off, m, sizeof(float) * n, hipMemcpyHostToDevice));
+    ORL_HIP(hipMemcpy(e.adam_v + off, v, sizeof(float) * n, hipMemcpyHostToDevice));
+  }
+  return 0;
+}
+int orl_adam_get(orl_engine* h, int run, int net, float* m, float* v, int64_t n) { return adam_xfer(h, run, net, m, v, n, true); }
+int orl_adam_set(orl_engine* h, int run, int net, const float* m, const float* v, int64_t n) {
+  return adam_xfer(h, run, net, const_cast<float*>(m), const_cast<float*>(v), n, false);
+}
+int orl_set_step_count(orl_engine* h, int64_t steps) {
+  Engine& e = h->e;
+  if (steps < 0) return fail("negative step count");
+  ORL_HIP(hipSetDevice(e.dev));
+  ORL_HIP(hipStreamSynchronize(e.stream));
+  const unsigned long long s = (unsigned long long)steps;
+  ORL_HIP(hipMemcpy(e.gstep, &s, sizeof(s), hipMemcpyHostToDevice));
+  e.step_host = s;
   return 0;
 }
 
@@ -1077,6 +1132,7 @@ int orl_buffer_load(orl_buffer* h, const float* obs, const float* act, const flo
   if (upload_padded(&b.rew, rew, n, 1, 1)) return -1;
   if (upload_padded(&b.term, term, n, 1, 1)) return -1;
   b.n = n;
+  b.gen++;               // the arrays moved: engines that captured them re-capture (orl_learn_n)
   return 0;
 }
 int64_t orl_buffer_size(orl_buffer* h) { return h->b.n; }
@@ -1141,14 +1197,12 @@ int orl_buffer_sample(orl_buffer* h, const int64_t* idx, int32_t batch, uint64_t
   return 0;
 }
 int orl_engine_attach_buffer(orl_engine* h, orl_buffer* b) {
-  if (!b) { h->e.buf = nullptr; return 0; }
+  if (!b) { h->e.buf = nullptr; h->e.drop_graphs(); return 0; }
   if (b->b.od != h->e.od || b->b.ad != h->e.ad) return fail("attach_buffer: obs/act dims differ from the engine's");
   if (b->b.dev != h->e.dev) return fail("attach_buffer: buffer lives on another device");
   h->e.buf = &b->b;
-  for (int i = 0; i < 2; ++i) {   // captured graphs hold the old dataset pointers
-    if (h->e.graph_exec[i]) { hipGraphExecDestroy(h->e.graph_exec[i]); h->e.graph_exec[i] = nullptr; }
-    if (h->e.graph[i]) { hipGraphDestroy(h->e.graph[i]); h->e.graph[i] = nullptr; }
-  }
+  h->e.buf_gen = b->b.gen;
+  h->e.drop_graphs();             // captured graphs hold the old dataset pointers
   return 0;
 }
 
@@ -1199,6 +1253,11 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   if (n_steps <= 0) return fail("n_steps must be positive");
   if (!e.buf || !e.buf->obs) return fail("orl_learn_n: no replay buffer attached");
   ORL_HIP(hipMemsetAsync(e.metrics_sum, 0, sizeof(float) * e.R * e.nm, e.stream));
+  if (e.buf_gen != e.buf->gen) {       // the buffer was reloaded since the graphs were captured: they hold freed pointers and the old size
+    ORL_HIP(hipStreamSynchronize(e.stream));
+    e.drop_graphs();
+    e.buf_gen = e.buf->gen;
+  }
   const bool graphable = e.use_graph && !e.prof_on;
   if (graphable) {
     for (int v = 0; v < e.n_variants(); ++v) {
@@ -1257,6 +1316,35 @@ int64_t orl_debug_read(orl_engine* h, int run, const char* name, float* host, in
   if (hipMemcpy2D(host, sizeof(float) * t.cols, t.m.p + run * t.m.rs, sizeof(float) * t.m.pitch, sizeof(float) * t.cols, t.rows,
                   hipMemcpyDeviceToHost) != hipSuccess) { fail("tap copy"); return -1; }
   return n;
+}
+
+// gradient of the LAST step w.r.t. every parameter of `net` (state_dict order, orl_net_floats values): the split-K slabs the
+// backward kernels wrote, summed per tensor group (double accumulation on the host; k_adam sums the same slabs in fp32)
+int orl_debug_grads(orl_engine* h, int run, int net, float* host, int64_t n) {
+  Engine& e = h->e;
+  if (run < 0 || run >= e.R) return fail("bad run");
+  if (net < 0 || net >= ORL_NUM_NETS || !e.lay[net].present || e.net_is_target[net]) return fail("orl_debug_grads: not a trainable net");
+  const NetLayout& l = e.lay[net];
+  if (n != l.size) return fail("orl_debug_grads: bad size");
+  const auto& segs = e.last_segs[net];
+  if (segs.empty()) return fail("orl_debug_grads: no optimizer step has run for this net yet");
+  int maxs = 1;
+  for (auto& sg : segs) maxs = std::max(maxs, sg.second);
+  ORL_HIP(hipSetDevice(e.dev));
+  ORL_HIP(hipStreamSynchronize(e.stream));
+  std::vector<float> tmp((size_t)maxs * l.size);
+  const float* src = e.grads + (long)run * e.max_slab * e.P_train + e.net_off[net];
+  ORL_HIP(hipMemcpy2D(tmp.data(), sizeof(float) * l.size, src, sizeof(float) * e.P_train, sizeof(float) * l.size, maxs, hipMemcpyDeviceToHost));
+  long i = 0;
+  for (auto& sg : segs) {
+    for (; i < sg.first && i < l.size; ++i) {
+      double a = 0.0;
+      for (int k = 0; k < sg.second; ++k) a += tmp[(size_t)k * l.size + i];
+      host[i] = (float)a;
+    }
+  }
+  for (; i < l.size; ++i) host[i] = tmp[i];
+  return 0;
 }
 
 int orl_profile_enable(orl_engine* h, int on) { h->e.prof_on = on != 0; return 0; }

@@ -21,6 +21,9 @@ MAX_HIDDEN, MAX_METRICS, MAX_NOISE = 4, 8, 6
 NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC1_OLD, NET_CRITIC2_OLD, NET_CRITIC_V, NET_ACTOR_OLD = range(7)
 NUM_NETS = 7
 SCALAR_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA, SCALAR_ALPHA = 0, 1, 2
+SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA_M, SCALAR_CQL_LOG_ALPHA_V, SCALAR_LAST_ACTOR_LOSS = 3, 4, 5, 6, 7
+ALL_SCALARS = (SCALAR_LOG_ALPHA, SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA_M,
+               SCALAR_CQL_LOG_ALPHA_V, SCALAR_LAST_ACTOR_LOSS, SCALAR_ALPHA)      # set order: ALPHA last (LOG_ALPHA derives it)
 OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V = range(5)
 
 # symbols include/orl_engine.h declares (checked by tests/test_abi.py)
@@ -28,9 +31,9 @@ ABI_SYMBOLS = [
     "orl_last_error", "orl_version", "orl_config_default", "orl_arena_floats", "orl_engine_create",
     "orl_engine_destroy", "orl_engine_sync", "orl_net_present", "orl_net_floats", "orl_net_num_tensors",
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
-    "orl_set_lr", "orl_reset_optimizers", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
+    "orl_set_lr", "orl_reset_optimizers", "orl_adam_get", "orl_adam_set", "orl_set_step_count", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
     "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
-    "orl_debug_read", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
+    "orl_debug_read", "orl_debug_grads", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
 ]
 
 
@@ -108,6 +111,9 @@ def load_library(path: Optional[str] = None):
     lib.orl_scalar_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.orl_set_lr.argtypes = [C.c_void_p, C.c_int, C.c_float]
     lib.orl_reset_optimizers.argtypes = [C.c_void_p]
+    lib.orl_adam_get.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.orl_adam_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.orl_set_step_count.argtypes = [C.c_void_p, C.c_int64]
     lib.orl_buffer_create.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     lib.orl_buffer_destroy.argtypes = [C.c_void_p]
     lib.orl_buffer_destroy.restype = None
@@ -126,6 +132,7 @@ def load_library(path: Optional[str] = None):
     lib.orl_step_count.restype = C.c_int64
     lib.orl_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64]
     lib.orl_debug_read.restype = C.c_int64
+    lib.orl_debug_grads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
     lib.orl_debug_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_int, C.c_int]
     lib.orl_debug_gemm_time.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_float)]
     lib.orl_profile_enable.argtypes = [C.c_void_p, C.c_int]
@@ -243,6 +250,38 @@ class Engine:
     def reset_optimizers(self):
         _check(self.lib.orl_reset_optimizers(self._h), "orl_reset_optimizers")
 
+    def adam_state(self, run: int, net: int):
+        """(exp_avg, exp_avg_sq) of the net's Adam optimizer, flat in state_dict order."""
+        n = self.net_floats(net)
+        m, v = np.empty(n, np.float32), np.empty(n, np.float32)
+        _check(self.lib.orl_adam_get(self._h, run, net, m.ctypes.data, v.ctypes.data, n), "orl_adam_get")
+        return m, v
+
+    def set_adam_state(self, run: int, net: int, m, v):
+        m, v = _f32(m).ravel(), _f32(v).ravel()
+        _check(self.lib.orl_adam_set(self._h, run, net, m.ctypes.data, v.ctypes.data, m.size), "orl_adam_set")
+
+    def set_step_count(self, steps: int):
+        _check(self.lib.orl_set_step_count(self._h, int(steps)), "orl_set_step_count")
+
+    def trainable_nets(self) -> List[int]:
+        return [n for n in range(NUM_NETS) if self.net_present(n) and n in (NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC_V)]
+
+    def optimizer_state(self, run: int = 0) -> Dict:
+        """Everything torch.optim state_dict()s would hold for this run: per-net Adam moments, the scalar optimizers, the step count."""
+        st = {"step": self.step_count(), "adam": {n: self.adam_state(run, n) for n in self.trainable_nets()}, "scalars": {}}
+        for w in ALL_SCALARS:
+            st["scalars"][w] = self.get_scalar(run, w)
+        return st
+
+    def load_optimizer_state(self, st: Dict, run: int = 0):
+        for n, (m, v) in st["adam"].items():
+            self.set_adam_state(run, n, m, v)
+        for w in ALL_SCALARS:
+            if w in st["scalars"]:
+                self.set_scalar(run, w, st["scalars"][w])
+        self.set_step_count(st["step"])
+
     # ---- buffer ----
     def attach_buffer(self, buf: "DeviceBuffer"):
         _check(self.lib.orl_engine_attach_buffer(self._h, buf._h if buf is not None else None), "orl_engine_attach_buffer")
@@ -296,6 +335,12 @@ class Engine:
         if n < 0:
             raise RuntimeError(f"orl_debug_read({name}) failed: {last_error()}")
         return buf[:n].copy()
+
+    def debug_grads(self, run: int, net: int) -> Dict[str, np.ndarray]:
+        """Gradients of the last step for every tensor of ``net`` (reference: ``param.grad`` before ``optimizer.step()``)."""
+        flat = np.empty(self.net_floats(net), dtype=np.float32)
+        _check(self.lib.orl_debug_grads(self._h, run, net, flat.ctypes.data, flat.size), "orl_debug_grads")
+        return {name: flat[off:off + int(np.prod(shape))].reshape(shape).copy() for name, off, shape in self.net_tensors(net)}
 
     def profile_enable(self, on: bool):
         self.lib.orl_profile_enable(self._h, 1 if on else 0)

@@ -12,8 +12,9 @@ There is no CPU fallback: without the native library or a GPU, ``learn`` raises.
 """
 from __future__ import annotations
 
+import os
 from copy import deepcopy
-from typing import Dict, List, Optional
+from typing import Callable, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -58,6 +59,17 @@ def _adam_hyper(optim: torch.optim.Optimizer):
     return float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])
 
 
+_BIND_COUNTER = 0
+
+
+def _mix64(x: int) -> int:
+    """splitmix64 finaliser: spreads (torch seed, bind counter) over the 64-bit Philox key space"""
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
 class EnginePolicy(BasePolicy):
     ALGO: str = ""
 
@@ -68,6 +80,11 @@ class EnginePolicy(BasePolicy):
         self._bound_batch = None
         self._lr_pushed: Dict[int, float] = {}
         self._attached = None
+        self._n_runs = 1
+        self._run_init = None
+        self._seed: Optional[int] = None
+        self._precision = int(os.environ.get("ORL_PRECISION", "0"))
+        self._cur_run = 0
 
     # -- subclass hooks ------------------------------------------------------------------
     def _nets(self) -> Dict[int, nn.Module]:
@@ -75,6 +92,10 @@ class EnginePolicy(BasePolicy):
 
     def _optims(self) -> Dict[int, torch.optim.Optimizer]:
         raise NotImplementedError
+
+    def _all_optims(self) -> List[torch.optim.Optimizer]:
+        """every optimizer the reference constructor received (validated; ``_optims`` lists the ones whose lr is read)"""
+        return list(self._optims().values())
 
     def _config(self) -> Dict:
         raise NotImplementedError
@@ -84,6 +105,37 @@ class EnginePolicy(BasePolicy):
 
     def _before_unbind(self) -> None:
         pass
+
+    # -- engine options (before the first learn(), or any time: the engine is rebuilt around the current state) --------
+    def set_engine_options(self, n_runs: Optional[int] = None, seed: Optional[int] = None, precision: Optional[int] = None,
+                           run_init: Optional[Callable[[int], Dict[str, Dict[str, torch.Tensor]]]] = None) -> "EnginePolicy":
+        """``n_runs``: independent runs (seeds) this policy object trains together -- every kernel launch updates all of them
+        (the reference's analogue is N separate processes, tune_example/tune_mopo.py:222-239).  Run 0 starts from the modules'
+        current parameters; run r > 0 from ``run_init(r)`` ({net attribute name: state_dict}) or, by default, from the modules'
+        own ``reset_parameters()`` under ``torch.manual_seed(seed + r)`` -- i.e. what building the networks under another seed
+        gives (custom initialisations such as run_iql.py:121-125 / run_edac.py:100-103 need ``run_init``).
+        ``seed``: key of the device sampler / noise streams (default: derived from ``torch.initial_seed()`` and a per-process
+        bind counter, so launcher seeds give independent streams and a re-bind never replays one).
+        ``precision``: 0 exact fp32 MFMA (default), 1 split-bf16 MFMA (same 1e-4 parity gate, ~4x faster)."""
+        if self._eng is not None:
+            self._unbind()
+        if n_runs is not None:
+            if n_runs < 1:
+                raise ValueError("n_runs must be >= 1")
+            self._n_runs = int(n_runs)
+        if seed is not None:
+            self._seed = int(seed)
+        if precision is not None:
+            if precision not in (0, 1):
+                raise ValueError("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)")
+            self._precision = int(precision)
+        if run_init is not None:
+            self._run_init = run_init
+        return self
+
+    @property
+    def n_runs(self) -> int:
+        return self._n_runs
 
     # -- engine binding ------------------------------------------------------------------
     def _device(self) -> torch.device:
@@ -96,22 +148,59 @@ class EnginePolicy(BasePolicy):
         dev = torch.device(dev)
         return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
 
+    def _engine_seed(self) -> int:
+        global _BIND_COUNTER
+        _BIND_COUNTER += 1
+        base = self._seed if self._seed is not None else torch.initial_seed()
+        return _mix64((int(base) & 0xFFFFFFFFFFFFFFFF) ^ _mix64(_BIND_COUNTER))
+
+    def _fresh_run_params(self, run: int) -> Dict[int, Dict[str, torch.Tensor]]:
+        """initial parameters of run > 0, keyed by net id"""
+        nets = self._nets()
+        if self._run_init is not None:
+            given = self._run_init(run)
+            by_mod = {id(getattr(self, k)): v for k, v in given.items()}
+            out = {}
+            for nid, mod in nets.items():
+                if id(mod) in by_mod:
+                    out[nid] = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in by_mod[id(mod)].items()}
+            return out
+        base = self._seed if self._seed is not None else torch.initial_seed()
+        rng_state = torch.get_rng_state()
+        try:
+            torch.manual_seed((int(base) + run) & 0x7FFFFFFFFFFFFFFF)
+            out = {}
+            trainable = [nid for nid in nets if nid in (_engine.NET_ACTOR, _engine.NET_CRITIC1, _engine.NET_CRITIC2, _engine.NET_CRITIC_V)]
+            for nid in trainable:
+                m = deepcopy(nets[nid]).cpu()
+                for sub in m.modules():
+                    if hasattr(sub, "reset_parameters"):
+                        sub.reset_parameters()
+                out[nid] = {k: v.detach().clone() for k, v in m.named_parameters()}
+        finally:
+            torch.set_rng_state(rng_state)
+        return out
+
+    _TARGET_OF = {_engine.NET_CRITIC1_OLD: _engine.NET_CRITIC1, _engine.NET_CRITIC2_OLD: _engine.NET_CRITIC2, _engine.NET_ACTOR_OLD: _engine.NET_ACTOR}
+
     def _bind(self, batch_size: int) -> None:
         if self._eng is not None and self._bound_batch == batch_size:
             return
-        saved_steps = None
-        if self._eng is not None:        # batch size changed: rebuild around the current weights
-            self._unbind()
+        carried = None
+        if self._eng is not None:        # batch size changed: rebuild around the current weights AND optimizer state
+            carried = self._unbind()
         dev = self._device()
         over = dict(self._config())
         betas, eps = None, None
-        for oid, opt in self._optims().items():
+        for opt in self._all_optims():
             lr, b, e = _adam_hyper(opt)
             if betas is None:
                 betas, eps = b, e
             elif (b, e) != (betas, eps):
                 raise NotImplementedError("all optimizers of a policy must share Adam betas/eps")
-        over.update(batch_size=int(batch_size), n_runs=1, device=dev.index, adam_beta1=betas[0], adam_beta2=betas[1], adam_eps=eps)
+        R = self._n_runs
+        over.update(batch_size=int(batch_size), n_runs=R, device=dev.index, adam_beta1=betas[0], adam_beta2=betas[1], adam_eps=eps,
+                    precision=self._precision, seed=self._engine_seed())
         cfg = _engine.default_config(self.ALGO, **over)
         n = _engine.load_library().orl_arena_floats(cfg)
         if n <= 0:
@@ -121,35 +210,89 @@ class EnginePolicy(BasePolicy):
         torch.cuda.synchronize(dev)
         self._eng = _engine.Engine(cfg)
         self._bound_batch = batch_size
-        base = self._arena.data_ptr()
-        for nid, mod in self._nets().items():
+        nets = self._nets()
+        # run 0 (or, on a re-bind, every run) <- current parameters; fresh runs <- their own initialisation
+        for nid, mod in nets.items():
             mod.to(dev)
             for m in mod.modules():
                 if hasattr(m, "device") and isinstance(getattr(m, "device"), torch.device):
                     m.device = dev
-            off0 = (self._eng.net_ptr(0, nid) - base) // 4
-            params = dict(mod.named_parameters())
-            for name, off, shape in self._eng.net_tensors(nid):
-                p = params[name]
-                if tuple(p.shape) != tuple(shape):
-                    raise ValueError(f"{name}: module shape {tuple(p.shape)} != engine shape {tuple(shape)}")
-                view = self._arena[off0 + off: off0 + off + p.numel()].view(shape)
-                view.copy_(p.data.to(dev))
-                p.data = view
+        for r in range(R):
+            if carried is not None:
+                params = carried["params"][r]
+            elif r == 0:
+                params = {nid: dict(mod.named_parameters()) for nid, mod in nets.items()}
+            else:
+                fresh = self._fresh_run_params(r)
+                params = {}
+                for nid, mod in nets.items():
+                    src = fresh.get(nid)
+                    if src is None and nid in self._TARGET_OF:      # deepcopy of the freshly initialised critic (sac.py:29-33)
+                        src = fresh.get(self._TARGET_OF[nid])
+                    params[nid] = src if src is not None else dict(mod.named_parameters())
+            for nid in nets:
+                self._write_net(r, nid, params[nid])
+        self._cur_run = -1
+        self.select_run(0)
         torch.cuda.synchronize(dev)
         self._lr_pushed = {}
         self._push_lrs()
-        self._after_bind()
+        if carried is not None:
+            for r in range(R):
+                self._eng.load_optimizer_state(carried["opt"][r], r)
+        else:
+            self._after_bind()
         self._attached = None
 
-    def _unbind(self) -> None:
-        """Detach module parameters from the arena (clone) and drop the engine."""
+    def _net_views(self, run: int, nid: int):
+        base = self._arena.data_ptr()
+        off0 = (self._eng.net_ptr(run, nid) - base) // 4
+        for name, off, shape in self._eng.net_tensors(nid):
+            numel = int(np.prod(shape))
+            yield name, self._arena[off0 + off: off0 + off + numel].view(shape)
+
+    def _write_net(self, run: int, nid: int, params) -> None:
+        for name, view in self._net_views(run, nid):
+            p = params[name]
+            src = p.data if isinstance(p, torch.nn.Parameter) else torch.as_tensor(p)
+            if tuple(src.shape) != tuple(view.shape):
+                raise ValueError(f"{name}: module shape {tuple(src.shape)} != engine shape {tuple(view.shape)}")
+            view.copy_(src.to(view.device, dtype=torch.float32))
+
+    def select_run(self, run: int) -> None:
+        """Point the torch modules (``state_dict``, ``select_action``, checkpoints) at run ``run``'s live parameters."""
+        if self._eng is None:
+            if run != 0:
+                raise RuntimeError("select_run before the first learn(): only run 0 exists yet")
+            return
+        if not 0 <= run < self._n_runs:
+            raise IndexError(f"run {run} out of range (n_runs = {self._n_runs})")
+        if run == self._cur_run:
+            return
+        for nid, mod in self._nets().items():
+            params = dict(mod.named_parameters())
+            for name, view in self._net_views(run, nid):
+                params[name].data = view
+        self._cur_run = run
+        self._on_select_run(run)
+
+    def _on_select_run(self, run: int) -> None:
+        pass
+
+    def _unbind(self):
+        """Detach module parameters from the arena (clone) and drop the engine; returns what a re-bind carries over."""
+        self.select_run(0)
         self._before_unbind()
+        carried = {"params": [], "opt": []}
+        for r in range(self._n_runs):
+            carried["params"].append({nid: {name: v.clone() for name, v in self._net_views(r, nid)} for nid in self._nets()})
+            carried["opt"].append(self._eng.optimizer_state(r))
         for mod in self._nets().values():
             for p in mod.parameters():
                 p.data = p.data.clone()
         self._eng.close()
         self._eng, self._arena, self._bound_batch = None, None, None
+        return carried
 
     def _push_lrs(self) -> None:
         for oid, opt in self._optims().items():
@@ -167,32 +310,47 @@ class EnginePolicy(BasePolicy):
         for nid, m in self._nets().items():
             nn.Module.train(m, False)
 
+    def _result(self, m: np.ndarray) -> Dict[str, float]:
+        """metric table [n_runs][n_metrics] -> the reference's result dict; with several runs the plain keys hold the mean over
+        runs and ``run<i>/<key>`` the individual values"""
+        names = self._eng.metric_names
+        if self._n_runs == 1:
+            return {k: float(v) for k, v in zip(names, m[0])}
+        out = {k: float(v) for k, v in zip(names, m.mean(axis=0))}
+        for r in range(self._n_runs):
+            for k, v in zip(names, m[r]):
+                out[f"run{r}/{k}"] = float(v)
+        return out
+
     def learn(self, batch: Dict, noise: Optional[List] = None) -> Dict[str, float]:
         """One gradient step on ``batch`` (the dict ``ReplayBuffer.sample`` returns).  Synchronous, like the
         reference's ``.item()`` calls; noise is drawn on the device (Philox) unless ``noise`` supplies the arrays of
-        include/orl_engine.h's orl_noise in the reference's draw order (teacher-forced parity runs)."""
+        include/orl_engine.h's orl_noise in the reference's draw order (teacher-forced parity runs).  With ``n_runs`` > 1 the
+        arrays either carry a leading run dimension or are shared by all runs."""
         obs = batch["observations"]
-        B = int(obs.shape[0])
+        R = self._n_runs
+        per_run = R > 1 and obs.dim() == 3 if torch.is_tensor(obs) else (R > 1 and np.ndim(obs) == 3)
+        B = int(obs.shape[1] if per_run else obs.shape[0])
         self._bind(B)
         dev = self._arena.device
         keep = []
         ptrs = {}
-        for k in ("observations", "actions", "next_observations", "rewards", "terminals"):
-            t = torch.as_tensor(batch[k], dtype=torch.float32, device=dev).contiguous()
+
+        def dev_array(x):
+            t = torch.as_tensor(x, dtype=torch.float32, device=dev)
+            if R > 1 and not per_run:
+                t = t.unsqueeze(0).expand(R, *t.shape)
+            t = t.contiguous()
             keep.append(t)
-            ptrs[k] = t.data_ptr()
-        torch.cuda.current_stream(dev).synchronize()
+            return t.data_ptr()
+        for k in ("observations", "actions", "next_observations", "rewards", "terminals"):
+            ptrs[k] = dev_array(batch[k])
         self._push_lrs()
         nz = None
         if noise is not None:
-            nz = []
-            for a in noise:
-                t = torch.as_tensor(a, dtype=torch.float32, device=dev).contiguous()
-                keep.append(t)
-                nz.append(t.data_ptr())
-            torch.cuda.current_stream(dev).synchronize()
-        m = self._eng.step(ptrs, nz, on_device=True)[0]
-        return {k: float(v) for k, v in zip(self._eng.metric_names, m)}
+            nz = [dev_array(a) for a in noise]
+        torch.cuda.current_stream(dev).synchronize()
+        return self._result(self._eng.step(ptrs, nz, on_device=True))
 
     def learn_n(self, n_steps: int, buffer, batch_size: int = 256) -> Dict[str, float]:
         """``n_steps`` x (sample -> learn) fused on the device (MFPolicyTrainer's inner loop, mf_policy_trainer.py:52-60):
@@ -206,7 +364,15 @@ class EnginePolicy(BasePolicy):
         self._push_lrs()
         m, ms = self._eng.learn_n(int(n_steps))
         self.last_learn_n_ms = ms
-        return {k: float(v) for k, v in zip(self._eng.metric_names, m[0])}
+        return self._result(m)
+
+    def run_state_dict(self, run: int) -> Dict[str, torch.Tensor]:
+        """``state_dict()`` of one run (a copy; the live modules keep pointing at the run selected before)."""
+        cur = max(self._cur_run, 0)
+        self.select_run(run)
+        sd = {k: v.detach().clone() for k, v in self.state_dict().items()}
+        self.select_run(cur)
+        return sd
 
     @property
     def engine(self) -> Optional[_engine.Engine]:

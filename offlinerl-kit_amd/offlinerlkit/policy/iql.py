@@ -37,6 +37,9 @@ class IQLPolicy(EnginePolicy):
     def _optims(self):
         return {_engine.OPT_ACTOR: self.actor_optim, _engine.OPT_CRITIC: self.critic_q1_optim, _engine.OPT_CRITIC_V: self.critic_v_optim}
 
+    def _all_optims(self):
+        return [self.actor_optim, self.critic_q1_optim, self.critic_q2_optim, self.critic_v_optim]
+
     def _config(self) -> Dict:
         od, hid = _backbone_dims(self.actor.backbone)
         ad = self.actor.dist_net.mu.out_features

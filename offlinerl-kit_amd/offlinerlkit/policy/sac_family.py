@@ -28,7 +28,7 @@ class _TanhGaussPolicy(EnginePolicy):
         if not self._is_auto_alpha:
             return self._fixed_alpha
         if self._eng is not None:
-            return self._eng.get_scalar(0, _engine.SCALAR_ALPHA)
+            return self._eng.get_scalar(max(self._cur_run, 0), _engine.SCALAR_ALPHA)
         return float(self._log_alpha.detach().exp())
 
     def _alpha_config(self) -> Dict:
@@ -38,16 +38,29 @@ class _TanhGaussPolicy(EnginePolicy):
 
     def _after_bind(self) -> None:
         if self._is_auto_alpha:
-            self._eng.set_scalar(0, _engine.SCALAR_LOG_ALPHA, float(self._log_alpha.detach().cpu().reshape(-1)[0]))
+            for r in range(self._n_runs):       # every run starts from the caller's log_alpha (run_cql.py:102: zeros)
+                self._eng.set_scalar(r, _engine.SCALAR_LOG_ALPHA, float(self._log_alpha.detach().cpu().reshape(-1)[0]))
 
     def _before_unbind(self) -> None:
         self.sync_scalars()
 
+    def _on_select_run(self, run: int) -> None:
+        self.sync_scalars()
+
     def sync_scalars(self) -> None:
-        """Copy the device-side log_alpha back into the caller's tensor (it is not an nn.Parameter in the reference)."""
+        """Copy the device-side log_alpha (of the selected run) back into the caller's tensor (it is not an nn.Parameter in the
+        reference)."""
         if self._eng is not None and self._is_auto_alpha:
             with torch.no_grad():
-                self._log_alpha.fill_(self._eng.get_scalar(0, _engine.SCALAR_LOG_ALPHA))
+                self._log_alpha.fill_(self._eng.get_scalar(max(self._cur_run, 0), _engine.SCALAR_LOG_ALPHA))
+
+    def _check_dist_net(self) -> None:
+        dn = self.actor.dist_net
+        if not getattr(dn, "_c_sigma", False) or not dn._unbounded:
+            raise NotImplementedError(f"{self.ALGO.upper()} engine expects TanhDiagGaussian(unbounded=True, conditioned_sigma=True)")
+        if float(dn._sigma_min) != -5.0 or float(dn._sigma_max) != 2.0:
+            raise NotImplementedError("the HIP tanh-Gaussian head clamps log-sigma to [-5, 2] (dist_module.py:57-58 defaults); "
+                                      f"got [{dn._sigma_min}, {dn._sigma_max}]")
 
     def actforward(self, obs, deterministic: bool = False):
         dist = self.actor(obs)
@@ -64,6 +77,9 @@ class _TanhGaussPolicy(EnginePolicy):
         if self._is_auto_alpha:
             o[_engine.OPT_ALPHA] = self.alpha_optim
         return o
+
+    def _all_optims(self):
+        return list(self._optims().values()) + [getattr(self, n) for n in ("critic2_optim",) if hasattr(self, n)]
 
 
 class CQLPolicy(_TanhGaussPolicy):
@@ -107,8 +123,9 @@ class CQLPolicy(_TanhGaussPolicy):
         od, hid = _backbone_dims(self.actor.backbone)
         cin, chid = _backbone_dims(self.critic1.backbone)
         ad = self.actor.dist_net.mu.out_features
-        if chid != hid or cin != od + ad or not getattr(self.actor.dist_net, "_c_sigma", False) or not self.actor.dist_net._unbounded:
-            raise NotImplementedError("CQL engine expects TanhDiagGaussian(unbounded=True, conditioned_sigma=True) and equal hidden dims")
+        self._check_dist_net()
+        if chid != hid or cin != od + ad:
+            raise NotImplementedError("CQL engine expects actor and critics to share hidden dims")
         c = dict(obs_dim=od, act_dim=ad, hidden=hid, gamma=self._gamma, tau=self._tau,
                  actor_lr=float(self.actor_optim.param_groups[0]["lr"]), critic_lr=float(self.critic1_optim.param_groups[0]["lr"]),
                  cql_weight=self._cql_weight, temperature=self._temperature, max_q_backup=int(bool(self._max_q_backup)),
@@ -121,12 +138,13 @@ class CQLPolicy(_TanhGaussPolicy):
 
     def _after_bind(self) -> None:
         super()._after_bind()
-        self._eng.set_scalar(0, _engine.SCALAR_CQL_LOG_ALPHA, float(self.cql_log_alpha.reshape(-1)[0]))
+        for r in range(self._n_runs):
+            self._eng.set_scalar(r, _engine.SCALAR_CQL_LOG_ALPHA, float(self.cql_log_alpha.reshape(-1)[0]))
 
     def sync_scalars(self) -> None:
         super().sync_scalars()
         if self._eng is not None:
-            self.cql_log_alpha.fill_(self._eng.get_scalar(0, _engine.SCALAR_CQL_LOG_ALPHA))
+            self.cql_log_alpha.fill_(self._eng.get_scalar(max(self._cur_run, 0), _engine.SCALAR_CQL_LOG_ALPHA))
 
 
 class EDACPolicy(_TanhGaussPolicy):
@@ -158,6 +176,7 @@ class EDACPolicy(_TanhGaussPolicy):
     def _config(self) -> Dict:
         od, hid = _backbone_dims(self.actor.backbone)
         ad = self.actor.dist_net.mu.out_features
+        self._check_dist_net()
         if list(self.critics.hidden_dims) != list(hid) or self.critics.obs_dim != od or self.critics.action_dim != ad:
             raise NotImplementedError("EDAC engine expects the ensemble critics to share the actor's hidden dims")
         c = dict(obs_dim=od, act_dim=ad, hidden=hid, gamma=self._gamma, tau=self._tau,

@@ -45,9 +45,14 @@ class TD3BCPolicy(EnginePolicy):
     def _optims(self):
         return {_engine.OPT_ACTOR: self.actor_optim, _engine.OPT_CRITIC: self.critic1_optim}
 
+    def _all_optims(self):
+        return [self.actor_optim, self.critic1_optim, self.critic2_optim]
+
     def _config(self) -> Dict:
         od, hid = _backbone_dims(self.actor.backbone)
         ad = self.actor.last.out_features
+        if float(getattr(self.actor, "_max", self._max_action)) != float(self._max_action):
+            raise NotImplementedError("Actor(max_action) and TD3BCPolicy(max_action) differ: learn() and select_action would disagree")
         cin, chid = _backbone_dims(self.critic1.backbone)
         if cin != od + ad or chid != hid:
             raise NotImplementedError("TD3BC engine expects actor and critics to share hidden dims")

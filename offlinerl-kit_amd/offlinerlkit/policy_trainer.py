@@ -7,6 +7,10 @@ checkpoint) and the same return value.  Two inner loops:
   * ``fused=True`` (default when the policy offers ``learn_n`` and the buffer is HBM-resident): the whole epoch's
     sample -> learn chain runs on the device and only the epoch means come back — the values ``logkv_mean`` would
     have accumulated (only per-epoch means are ever consumed).
+Evaluation: ``eval_env`` may be ONE env (the reference's sequential loop, verbatim) or a list of envs, which are stepped in
+lockstep with one batched ``select_action`` forward per step under the same episode accounting.
+Several runs per policy object (``policy.n_runs`` > 1, BASELINE config 5): the epoch's training is still one ``learn_n``; every
+run is evaluated, logged as ``run<i>/<key>`` (plain keys = mean over runs) and checkpointed as ``policy_run<i>.pth``.
 Multi-GPU: independent runs, one process per GPU (replicas only).  When ``torch.distributed`` is initialised the
 per-epoch metric vector of every rank is all-gathered (RCCL over xGMI on GPUs, gloo on CPU) so rank 0 can log
 all runs; no other collective exists on this path.
@@ -83,18 +87,32 @@ class MFPolicyTrainer:
         start_time = time.time()
         num_timesteps = 0
         last_10_performance = deque(maxlen=10)
+        n_runs = int(getattr(self.policy, "n_runs", 1))
         for e in range(1, self._epoch + 1):
             self.policy.train()
             num_timesteps += self._train_epoch(e)
             if self.lr_scheduler is not None:
                 self.lr_scheduler.step()
-            eval_info = self._evaluate()
+            if n_runs == 1:
+                eval_info = self._evaluate()
+            else:
+                per_run = []
+                for r in range(n_runs):
+                    self.policy.select_run(r)
+                    per_run.append(self._evaluate())
+                    self.logger.logkv(f"run{r}/eval/episode_reward", float(np.mean(per_run[-1]["eval/episode_reward"])))
+                    self.logger.logkv(f"run{r}/eval/episode_length", float(np.mean(per_run[-1]["eval/episode_length"])))
+                    if hasattr(self._score_env(), "get_normalized_score"):
+                        self.logger.logkv(f"run{r}/eval/normalized_episode_reward",
+                                          self._score_env().get_normalized_score(float(np.mean(per_run[-1]["eval/episode_reward"]))) * 100)
+                self.policy.select_run(0)
+                eval_info = {k: [x for info in per_run for x in info[k]] for k in per_run[0]}      # pooled over runs
             ep_reward_mean, ep_reward_std = np.mean(eval_info["eval/episode_reward"]), np.std(eval_info["eval/episode_reward"])
             ep_length_mean, ep_length_std = np.mean(eval_info["eval/episode_length"]), np.std(eval_info["eval/episode_length"])
             epoch_kv = dict(self.logger._name2val) if hasattr(self.logger, "_name2val") else {}
-            if hasattr(self.eval_env, "get_normalized_score"):
-                norm_ep_rew_mean = self.eval_env.get_normalized_score(ep_reward_mean) * 100
-                norm_ep_rew_std = self.eval_env.get_normalized_score(ep_reward_std) * 100
+            if hasattr(self._score_env(), "get_normalized_score"):
+                norm_ep_rew_mean = self._score_env().get_normalized_score(ep_reward_mean) * 100
+                norm_ep_rew_std = self._score_env().get_normalized_score(ep_reward_std) * 100
                 last_10_performance.append(norm_ep_rew_mean)
                 self.logger.logkv("eval/normalized_episode_reward", norm_ep_rew_mean)
                 self.logger.logkv("eval/normalized_episode_reward_std", norm_ep_rew_std)
@@ -107,13 +125,24 @@ class MFPolicyTrainer:
             self._gather({k: v for k, v in epoch_kv.items() if isinstance(v, (int, float, np.floating))})
             self.logger.set_timestep(num_timesteps)
             self.logger.dumpkvs()
-            torch.save(self.policy.state_dict(), os.path.join(self.logger.checkpoint_dir, "policy.pth"))
+            self._checkpoint(self.logger.checkpoint_dir, n_runs)
         self.logger.log("total time: {:.2f}s".format(time.time() - start_time))
-        torch.save(self.policy.state_dict(), os.path.join(self.logger.model_dir, "policy.pth"))
+        self._checkpoint(self.logger.model_dir, n_runs)
         self.logger.close()
         return {"last_10_performance": np.mean(last_10_performance)}
 
+    def _checkpoint(self, where: str, n_runs: int) -> None:
+        torch.save(self.policy.state_dict(), os.path.join(where, "policy.pth"))          # (run 0 when the policy carries several)
+        if n_runs > 1:
+            for r in range(n_runs):
+                torch.save(self.policy.run_state_dict(r), os.path.join(where, f"policy_run{r}.pth"))
+
+    def _score_env(self):
+        return self.eval_env[0] if isinstance(self.eval_env, (list, tuple)) else self.eval_env
+
     def _evaluate(self) -> Dict[str, List[float]]:
+        if isinstance(self.eval_env, (list, tuple)):
+            return self._evaluate_batched(list(self.eval_env))
         self.policy.eval()
         obs = self.eval_env.reset()
         done_eps: List[Dict[str, float]] = []
@@ -127,5 +156,36 @@ class MFPolicyTrainer:
                 done_eps.append({"episode_reward": ep_reward, "episode_length": ep_len})
                 ep_reward, ep_len = 0, 0
                 obs = self.eval_env.reset()
+        return {"eval/episode_reward": [d["episode_reward"] for d in done_eps],
+                "eval/episode_length": [d["episode_length"] for d in done_eps]}
+
+    def _evaluate_batched(self, envs) -> Dict[str, List[float]]:
+        """E envs in lockstep: one [E, obs_dim] deterministic forward per step instead of E one-row forwards.  Episode accounting
+        as in the reference loop: an env that finishes an episode is reset and keeps running while episodes are still owed; the
+        first ``eval_episodes`` episodes to START are the ones reported, in order of completion."""
+        self.policy.eval()
+        E = len(envs)
+        obs = [env.reset() for env in envs]
+        started = min(E, self._eval_episodes)
+        active = [i < started for i in range(E)]
+        ep_reward, ep_len = [0.0] * E, [0] * E
+        done_eps: List[Dict[str, float]] = []
+        while len(done_eps) < self._eval_episodes:
+            idx = [i for i in range(E) if active[i]]
+            batch = np.stack([np.asarray(obs[i], dtype=np.float32).reshape(-1) for i in idx])
+            actions = self.policy.select_action(batch, deterministic=True)
+            for j, i in enumerate(idx):
+                o, reward, terminal, _ = envs[i].step(np.asarray(actions[j]).flatten())
+                obs[i] = o
+                ep_reward[i] += reward
+                ep_len[i] += 1
+                if terminal:
+                    done_eps.append({"episode_reward": ep_reward[i], "episode_length": ep_len[i]})
+                    ep_reward[i], ep_len[i] = 0.0, 0
+                    if started < self._eval_episodes:
+                        started += 1
+                        obs[i] = envs[i].reset()
+                    else:
+                        active[i] = False
         return {"eval/episode_reward": [d["episode_reward"] for d in done_eps],
                 "eval/episode_length": [d["episode_length"] for d in done_eps]}

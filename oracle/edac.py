@@ -113,6 +113,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
     agr = nn.tanh_gauss_bwd(actor, cache, da, np.full((B, 1), alpha / f32(B), dtype=f32))
     nn.adam_step(actor, agr, state["opt"]["actor"], cfg["actor_lr"])
     aux["qas"] = qas
+    aux["actor_grads"] = agr
 
     result = OrderedDict()
     if cfg["auto_alpha"]:

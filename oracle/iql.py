@@ -59,6 +59,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise=None):
     gv, _ = nn.critic_bwd(vn, hv, dv, need_dx=False)
     nn.adam_step(vn, gv, state["opt"]["critic_v"], cfg["critic_v_lr"])
     aux["v"], aux["q_old"] = v, q
+    aux["critic_v_grads"] = gv
 
     # ---- critics (iql.py:100-116), target uses the UPDATED V ----
     q1, h1 = nn.critic_fwd(q1n, obs, act)
@@ -70,6 +71,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise=None):
     for name, net, qq, hh in (("critic_q1", q1n, q1, h1), ("critic_q2", q2n, q2, h2)):
         g, _ = nn.critic_bwd(net, hh, (f32(2) * (qq - target_q) / f32(B)).astype(f32), need_dx=False)
         nn.adam_step(net, g, state["opt"][name], cfg[f"critic_q_lr"])
+        aux[name + "_grads"] = g
     aux["q1"], aux["q2"], aux["target_q"] = q1, q2, target_q
 
     # ---- actor (iql.py:118-131): advantage-weighted BC ----
@@ -96,6 +98,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise=None):
         grads[f"backbone.model.{2 * l}.bias"] = db
     nn.adam_step(actor, grads, state["opt"]["actor"], cfg["actor_lr"])
     aux["exp_a"], aux["logp"] = exp_a, logp
+    aux["actor_grads"] = grads
 
     nn.polyak(q1o, q1n, cfg["tau"])
     nn.polyak(q2o, q2n, cfg["tau"])

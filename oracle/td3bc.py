@@ -62,6 +62,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
     for name, net, qq, hh in (("critic1", c1, q1, h1), ("critic2", c2, q2, h2)):
         g, _ = nn.critic_bwd(net, hh, (f32(2) * (qq - target_q) / f32(B)).astype(f32), need_dx=False)
         nn.adam_step(net, g, state["opt"][name], cfg["critic_lr"])
+        aux[name + "_grads"] = g
     aux.update(q1=q1, q2=q2, target_q=target_q)
 
     # ---- delayed actor + target sync (td3bc.py:106-116) ----
@@ -90,6 +91,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
         nn.polyak(c1o, c1, cfg["tau"])
         nn.polyak(c2o, c2, cfg["tau"])
         aux["q_pi"] = q
+        aux["actor_grads"] = grads
     state["cnt"] += 1
     result = OrderedDict([("loss/actor", float(state["last_actor_loss"])), ("loss/critic1", float(l1)), ("loss/critic2", float(l2))])
     return result, aux

@@ -256,3 +256,128 @@ def test_trainer_fused_epoch_with_cql_policy(tmp_path):
     assert pol.engine.step_count() == 50
     sd = torch.load(tmp_path / "model" / "policy.pth", weights_only=True)
     assert set(sd) == set(after)
+
+
+def _cql_buffer(c, n=3000, seed=4):
+    from offlinerlkit.buffer import ReplayBuffer
+    ds = synth.make_dataset(seed, n, c["obs_dim"], c["act_dim"])
+    buf = ReplayBuffer(n, (c["obs_dim"],), np.float32, c["act_dim"], np.float32, device=DEV)
+    buf.load_dataset(ds)
+    return buf
+
+
+def test_policy_device_streams_follow_the_launcher_seed():
+    """run_cql.py:75-79 seeds torch / numpy per experiment: policies built under different torch seeds must draw different
+    minibatch index and noise streams in the fused path, the same seed (same process history) the same ones, and a re-bind must
+    not replay a stream."""
+    from offlinerlkit.policy import base_policy as bp
+    c = synth.CQL_CASES["cql_tiny"]
+    buf = _cql_buffer(c)
+
+    def first_batch(torch_seed):
+        bp._BIND_COUNTER = 0                       # as in a fresh process
+        torch.manual_seed(torch_seed)
+        pol = build_cql("cql_tiny")[0]
+        pol.learn_n(1, buf, c["B"])
+        return pol, pol.engine.debug_read(0, "b_obs"), pol.engine.debug_read(0, "n_eps_actor")
+    p1, o1, e1 = first_batch(1)
+    p2, o2, e2 = first_batch(2)
+    p3, o3, e3 = first_batch(1)
+    assert not np.array_equal(o1, o2) and not np.array_equal(e1, e2)
+    assert np.array_equal(o1, o3) and np.array_equal(e1, e3)
+    p1.set_engine_options()                        # drops the engine; the next learn_n re-binds with a new stream key
+    p1.learn_n(1, buf, c["B"])
+    assert not np.array_equal(p1.engine.debug_read(0, "b_obs"), o1)
+
+
+def test_policy_rebind_on_batch_size_change_keeps_optimizer_state():
+    """The reference accepts any batch size per learn() call; the engine is rebuilt for a new one, and Adam's moments, the step
+    count (bias correction) and the scalar optimizers must survive: three steps with batch sizes 16, 16, 8 against the oracle."""
+    from oracle import cql as ocql
+    pol, cfg, st, batches, noises, _ = build_cql("cql_tiny")
+    pol.train()
+    N = cfg["num_repeat_actions"]
+
+    def cut(b, n, rows):
+        bb = {k: v[:rows] for k, v in b.items()}
+        nn_ = dict(eps_actor=n["eps_actor"][:rows], eps_next=n["eps_next"][:rows], u_rand=n["u_rand"][:rows * N],
+                   eps_pi=n["eps_pi"][:rows * N], eps_next_pi=n["eps_next_pi"][:rows * N])
+        return bb, nn_
+    for k, rows in enumerate((16, 16, 8)):
+        b, n = cut(batches[k], noises[k], rows)
+        res, _ = ocql.learn(st, cfg, b, n)
+        out = pol.learn(tb(b), noise=[n["eps_actor"], n["eps_next"], n["u_rand"], n["eps_pi"], n["eps_next_pi"]])
+        assert rel_err(np.array(list(out.values())), np.array(list(res.values())), floor=1e-2) < 1e-4, (k, out, res)
+    assert pol.engine.step_count() == 3
+    m, v = pol.engine.adam_state(0, 1)
+    assert np.abs(m).max() > 0 and np.abs(v).max() > 0
+    state_close(pol, st, ("actor", "critic1", "critic2", "critic1_old", "critic2_old"), 3e-6)
+
+
+def test_policy_rejects_configurations_the_kernels_hard_code():
+    from offlinerlkit.modules import ActorProb, Critic, TanhDiagGaussian
+    from offlinerlkit.nets import MLP
+    from offlinerlkit.policy import CQLPolicy
+    od, ad, hid = 5, 3, [32, 32]
+    actor = ActorProb(MLP(od, hid), TanhDiagGaussian(hid[-1], ad, unbounded=True, conditioned_sigma=True, sigma_min=-20.0), DEV)
+    c1, c2 = Critic(MLP(od + ad, hid), DEV), Critic(MLP(od + ad, hid), DEV)
+    pol = CQLPolicy(actor, c1, c2, torch.optim.Adam(actor.parameters(), lr=1e-4), torch.optim.Adam(c1.parameters(), lr=3e-4),
+                    torch.optim.Adam(c2.parameters(), lr=3e-4), action_space=Space(ad), alpha=0.2)
+    b = tb(synth.make_batch(np.random.RandomState(0), 16, od, ad))
+    with pytest.raises(NotImplementedError, match="log-sigma"):
+        pol.learn(b)
+    actor2 = ActorProb(MLP(od, hid), TanhDiagGaussian(hid[-1], ad, unbounded=True, conditioned_sigma=True), DEV)
+    pol2 = CQLPolicy(actor2, c1, c2, torch.optim.Adam(actor2.parameters(), lr=1e-4), torch.optim.Adam(c1.parameters(), lr=3e-4),
+                     torch.optim.Adam(c2.parameters(), lr=3e-4, betas=(0.5, 0.9)), action_space=Space(ad), alpha=0.2)
+    with pytest.raises(NotImplementedError, match="betas"):
+        pol2.learn(b)
+
+
+def test_multi_run_policy_through_the_reference_shaped_api(tmp_path):
+    """n_runs independent seeds behind ONE policy object (BASELINE config 5 keeps 8 per GPU): run 0 = the modules as built, runs
+    r > 0 re-initialised; learn_n reports the mean and run<i>/<key>; select_run re-points state_dict / select_action; the trainer
+    logs and checkpoints every run."""
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+    from offlinerlkit.utils.logger import Logger
+    R = 4
+    pol, cfg, st, batches, noises, log_alpha = build_cql("cql_tiny")
+    c = synth.CQL_CASES["cql_tiny"]
+    buf = _cql_buffer(c)
+    pol.set_engine_options(n_runs=R, seed=123)
+    out = pol.learn_n(5, buf, c["B"])
+    keys = pol.engine.metric_names
+    assert all(k in out for k in keys) and all(f"run{r}/{k}" in out for r in range(R) for k in keys)
+    for k in keys:
+        assert abs(out[k] - np.mean([out[f"run{r}/{k}"] for r in range(R)])) < 1e-5 * max(1.0, abs(out[k]))
+    sds = [pol.run_state_dict(r) for r in range(R)]
+    for r in range(1, R):
+        assert (sds[r]["actor.backbone.model.0.weight"] - sds[0]["actor.backbone.model.0.weight"]).abs().max() > 1e-3     # own initialisation
+    obs = batches[0]["observations"][:4]
+    pol.eval()
+    pol.select_run(0); a0 = pol.select_action(obs, deterministic=True)
+    pol.select_run(2); a2 = pol.select_action(obs, deterministic=True)
+    assert np.abs(a0 - a2).max() > 1e-4
+    assert torch.equal(pol.state_dict()["actor.dist_net.mu.bias"], sds[2]["actor.dist_net.mu.bias"])
+    # a shared batch through learn(): every run steps on it
+    res = pol.learn(tb(batches[0]))
+    assert f"run{R - 1}/loss/critic1" in res and np.isfinite(list(res.values())).all()
+
+    class Env(tf.FakeEnv):
+        def reset(self):
+            self.t = 0
+            return np.zeros(c["obs_dim"], np.float32)
+
+        def step(self, a):
+            self.t += 1
+            return np.full(c["obs_dim"], 0.1 * self.t, np.float32), float(a.sum()), self.t >= 3, {}
+    logger = Logger(str(tmp_path), {"policy_training_progress": "csv"})
+    trainer = MFPolicyTrainer(pol, Env(), buf, logger, epoch=2, step_per_epoch=10, batch_size=c["B"], eval_episodes=2)
+    trainer.train()
+    head = open(tmp_path / "record" / "policy_training_progress.csv").read().split("\n")[0].split(",")
+    for r in range(R):
+        assert f"run{r}/loss/critic1" in head and f"run{r}/eval/episode_reward" in head
+    assert "loss/critic1" in head and "eval/episode_reward" in head
+    for r in range(R):
+        sd = torch.load(tmp_path / "model" / f"policy_run{r}.pth", weights_only=True)
+        assert set(sd) == set(sds[0])
+    assert (tmp_path / "model" / "policy.pth").exists()

@@ -1,0 +1,258 @@
+"""GPU: the path bench.py times and MFPolicyTrainer uses by default -- ``orl_learn_n``: a captured hipGraph replayed per step,
+with ``k_prepare`` / ``k_gather`` drawing the minibatch indices and all noise on the device (Philox4x32-10 + Box-Muller).
+
+(a) teacher-forced replay: after every ``learn_n(1)`` the minibatch the device sampler drew and its noise arrays are read back
+    through debug taps and fed to the numpy oracle (reference: buffer.py:96-106 + <algo>.learn); the losses ``learn_n`` reports
+    must agree at the 1e-4 gate -- for the first launch of the graph and for its replays -- and an eager, host-fed engine
+    (``orl_step``, the path the fixture tests use) given the same arrays must agree with the graph to rounding.
+(b) the device RNG: moments and Kolmogorov-Smirnov tests of the N(0,1) and U[lo,hi) draws (dist_module.py:17-42, cql.py:138-140),
+    chi-square of the Philox minibatch indices over n (buffer.py:98, np.random.randint), independence across runs / steps.
+    There is no reference fixture for a device RNG stream (the reference draws with torch / numpy generators): these are
+    distributional checks -- "parity unpinned" for the streams themselves, pinned for everything computed from them.
+(c) a buffer reloaded after the graphs were captured is what the next ``learn_n`` samples (graphs re-captured)."""
+import numpy as np
+import pytest
+from scipy import stats
+
+import synth
+import test_gpu_algos as ta
+import test_gpu_cql as tc
+from helpers import clone_state, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(seed, n, od, ad):
+    ds = synth.make_dataset(seed, n, od, ad, term_p=0.05)
+    ds["terminals"] = ds["terminals"].astype(np.float32)
+    return ds
+
+
+def _buffer(ds, od, ad):
+    from offlinerlkit import _engine
+    buf = _engine.DeviceBuffer(od, ad)
+    buf.load(ds["observations"], ds["actions"], ds["next_observations"], ds["rewards"], ds["terminals"])
+    return buf
+
+
+def _tapped_batch(eng, r, B, od, ad):
+    return dict(observations=eng.debug_read(r, "b_obs").reshape(B, od), actions=eng.debug_read(r, "b_act").reshape(B, ad),
+                next_observations=eng.debug_read(r, "b_nobs").reshape(B, od), rewards=eng.debug_read(r, "b_rew").reshape(B, 1),
+                terminals=eng.debug_read(r, "b_term").reshape(B, 1))
+
+
+def _tapped_noise(algo, eng, r, c):
+    B, ad, od = c["B"], c["act_dim"], c["obs_dim"]
+    if algo == "iql":
+        return None
+    if algo == "td3bc":
+        return dict(eps_target=eng.debug_read(r, "n_eps_target").reshape(B, ad))
+    if algo == "edac":
+        return dict(eps_actor=eng.debug_read(r, "n_eps_actor").reshape(B, ad), eps_next=eng.debug_read(r, "n_eps_next").reshape(-1, ad))
+    N = c["N"]
+    BN = B * N
+    xc = eng.debug_read(r, "xc").reshape(B + 3 * BN, -1)          # the uniform actions are drawn straight into the critic input rows
+    return dict(eps_actor=eng.debug_read(r, "n_eps_actor").reshape(B, ad), eps_next=eng.debug_read(r, "n_eps_next").reshape(-1, ad),
+                u_rand=xc[B + 2 * BN:, od:od + ad].copy(), eps_pi=eng.debug_read(r, "n_eps_pi").reshape(BN, ad),
+                eps_next_pi=eng.debug_read(r, "n_eps_npi").reshape(BN, ad))
+
+
+def _noise_list(algo, n):
+    if algo == "cql":
+        return tc.noise_list(n)
+    return ta.noise_list(algo, n)
+
+
+def _make(algo, case, R, precision):
+    if algo == "cql":
+        eng, cfg, st, _, _ = tc.make_engine(case, n_runs=R, precision=precision)
+        from oracle import cql as mod
+        c = synth.CQL_CASES[case]
+    else:
+        eng, mod, cfg, st, _, _ = ta.make_engine(algo, case, n_runs=R, precision=precision)
+        c = getattr(synth, f"{algo.upper()}_CASES")[case]
+    return eng, mod, cfg, st, c
+
+
+@pytest.mark.parametrize("algo,case,precision", [("cql", "cql_tiny", 0), ("cql", "cql_halfcheetah", 1), ("iql", "iql_hopper", 1),
+                                                 ("td3bc", "td3bc_halfcheetah", 1), ("edac", "edac_tiny", 0), ("edac", "edac_walker2d", 1)])
+def test_learn_n_graph_replay_matches_oracle_and_eager_step(algo, case, precision):
+    R, steps = 3, 4
+    eng, mod, cfg, st, c = _make(algo, case, R, precision)
+    eager, _, _, _, _ = _make(algo, case, R, precision)
+    B, od, ad = c["B"], c["obs_dim"], c["act_dim"]
+    buf = _buffer(_dataset(11, 50_000, od, ad), od, ad)
+    eng.attach_buffer(buf)
+    states = [clone_state({k: v for k, v in st.items() if k not in ("opt", "cnt", "last_actor_loss")}) for _ in range(R)]
+    for s in states:
+        mod.init_opt(s)
+    keys = eng.metric_names
+    try:
+        seen = []
+        for k in range(steps):                      # k = 0: first launch of the freshly captured graph; k >= 1: replays
+            m, _ = eng.learn_n(1)
+            batches = [_tapped_batch(eng, r, B, od, ad) for r in range(R)]
+            noises = [_tapped_noise(algo, eng, r, c) for r in range(R)]
+            for r in range(R):
+                res, _ = mod.learn(states[r], cfg, batches[r], noises[r])
+                ora = np.array([res[x] for x in keys])
+                assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (algo, case, "step", k, "run", r, m[r], ora)
+            # the same arrays through the eager host-fed entry: same kernels, so the graph must reproduce it to rounding
+            bb = {kk: np.stack([b[kk] for b in batches]) for kk in batches[0]}
+            nl = None if noises[0] is None else [np.stack(x) for x in zip(*[_noise_list(algo, n) for n in noises])]
+            me = eager.step(bb, nl if nl is not None else [])
+            assert rel_err(m, me, floor=1e-3) < 2e-6, (algo, case, k, np.abs(m - me).max())
+            seen.append(batches[0]["observations"].copy())
+            assert not np.array_equal(batches[0]["observations"], batches[R - 1]["observations"])      # runs draw their own batches
+        assert all(not np.array_equal(seen[0], x) for x in seen[1:])                                   # and fresh ones every step
+        assert eng.step_count() == steps
+    finally:
+        eng.close(); eager.close(); buf.close()
+
+
+def _moments_ok(x, what):
+    n = x.size
+    assert abs(x.mean()) < 5 / np.sqrt(n), (what, "mean", x.mean())
+    assert abs(x.var() - 1) < 5 * np.sqrt(2 / n), (what, "var", x.var())
+    assert abs(stats.skew(x)) < 5 * np.sqrt(6 / n), (what, "skew", stats.skew(x))
+    assert abs(stats.kurtosis(x)) < 5 * np.sqrt(24 / n), (what, "excess kurtosis", stats.kurtosis(x))
+
+
+def test_device_noise_is_standard_normal_and_uniform():
+    """> 1e6 device draws of each kind (32 runs x 3 steps of the full-size CQL engine): N(0,1) for the reparameterisation noise
+    (Box-Muller on Philox words), U[-1,1) for CQL's random actions; streams of different slots / runs / steps are independent."""
+    R = 32
+    eng, mod, cfg, st, c = _make("cql", "cql_halfcheetah", R, 1)
+    B, od, ad, N = c["B"], c["obs_dim"], c["act_dim"], c["N"]
+    buf = _buffer(_dataset(5, 20_000, od, ad), od, ad)
+    eng.attach_buffer(buf)
+    try:
+        normal, unif, per_step = [], [], []
+        for k in range(3):
+            eng.learn_n(1)
+            ns = [_tapped_noise("cql", eng, r, c) for r in range(R)]
+            normal += [n[x].ravel() for n in ns for x in ("eps_actor", "eps_next", "eps_pi", "eps_next_pi")]
+            unif += [n["u_rand"].ravel() for n in ns]
+            per_step.append(ns)
+        z = np.concatenate(normal).astype(np.float64)
+        u = np.concatenate(unif).astype(np.float64)
+        assert z.size > 1_000_000 and u.size > 1_000_000
+        _moments_ok(z, "normal")
+        assert stats.kstest(z, "norm").pvalue > 1e-3, stats.kstest(z, "norm")
+        assert np.abs(z).max() > 4.0 and np.isfinite(z).all()                    # the tails are there (24-bit uniforms reach 5.9 sigma)
+        assert u.min() >= -1.0 and u.max() < 1.0
+        assert stats.kstest(u, "uniform", args=(-1.0, 2.0)).pvalue > 1e-3
+        assert abs(u.mean()) < 5 * np.sqrt(1 / 3 / u.size) and abs(u.var() - 1 / 3) < 5 * np.sqrt(4 / 45 / u.size)
+        # independence: slots, neighbouring runs, consecutive steps
+        def corr(a, b):
+            return abs(np.corrcoef(a.ravel().astype(np.float64), b.ravel().astype(np.float64))[0, 1])
+        n0, n1 = per_step[0][0], per_step[0][1]
+        lim = 5 / np.sqrt(n0["eps_pi"].size)
+        assert corr(n0["eps_pi"], n0["eps_next_pi"]) < lim
+        assert corr(n0["eps_pi"], n1["eps_pi"]) < lim
+        assert corr(n0["eps_pi"], per_step[1][0]["eps_pi"]) < lim
+        assert corr(n0["eps_pi"], n0["u_rand"]) < lim
+        # Box-Muller pairs (cos / sin of one angle) are uncorrelated
+        e = n0["eps_pi"].ravel()
+        assert corr(e[0::2], e[1::2]) < 5 / np.sqrt(e.size / 2)
+    finally:
+        eng.close(); buf.close()
+
+
+@pytest.mark.parametrize("n", [1_000, 1_000_000, 2_000_000])
+def test_device_minibatch_indices_are_uniform_over_the_buffer(n):
+    """np.random.randint(0, size, B) restated on the device (buffer.py:98): the dataset's first observation column holds the row
+    index, so the sampled rows reveal the Philox indices.  Chi-square over 100 equal bins of [0, n) on > 3e5 draws, exact range,
+    every run / step draws a different vector.  Both samplers: ReplayBuffer.sample's k_gather and orl_learn_n's."""
+    import torch
+    from offlinerlkit import _engine
+    od, ad = 3, 2
+    obs = np.zeros((n, od), np.float32)
+    obs[:, 0] = np.arange(n, dtype=np.float32)              # exact in fp32 up to 2^24
+    z = np.zeros((n, ad), np.float32)
+    buf = _engine.DeviceBuffer(od, ad)
+    buf.load(obs, z, obs, np.zeros(n, np.float32), np.zeros(n, np.float32))
+    dev = torch.device("cuda:0")
+    Bs = 65536
+    out = dict(o=torch.empty(Bs, od, device=dev), a=torch.empty(Bs, ad, device=dev), n=torch.empty(Bs, od, device=dev),
+               r=torch.empty(Bs, device=dev), t=torch.empty(Bs, device=dev))
+    draws = []
+    for _ in range(5):
+        buf.sample_into(None, Bs, 77, out["o"].data_ptr(), out["a"].data_ptr(), out["n"].data_ptr(), out["r"].data_ptr(), out["t"].data_ptr())
+        draws.append(out["o"][:, 0].cpu().numpy().astype(np.int64))
+    assert not np.array_equal(draws[0], draws[1])
+
+    def uniform_ok(idx, what):
+        assert idx.min() >= 0 and idx.max() < n, (what, idx.min(), idx.max())
+        counts = np.bincount((idx * 100) // n, minlength=100)
+        p = stats.chisquare(counts).pvalue
+        assert p > 1e-4, (what, n, p)
+    uniform_ok(np.concatenate(draws), "ReplayBuffer.sample")
+    if n >= 1_000_000:
+        assert np.unique(np.concatenate(draws)).size > 0.8 * 5 * Bs          # with replacement, but no short cycle
+
+    # the learn_n sampler (k_gather for IQL: batch slots; same Philox indexing as k_prepare) -- 64 runs x 20 steps x 256 rows
+    R = 64
+    cfg = _engine.default_config("iql", obs_dim=od, act_dim=ad, hidden=[32, 32], batch_size=256, n_runs=R, seed=4242)
+    eng = _engine.Engine(cfg)
+    eng.attach_buffer(buf)
+    try:
+        got = []
+        for _ in range(20):
+            eng.learn_n(1)
+            got.append(np.stack([eng.debug_read(r, "b_obs").reshape(256, od)[:, 0] for r in range(R)]).astype(np.int64))
+        allidx = np.stack(got)                                              # (steps, runs, B)
+        uniform_ok(allidx.ravel(), "orl_learn_n sampler")
+        flat = allidx.reshape(-1, 256)
+        assert len({tuple(v) for v in flat}) == flat.shape[0]               # no run / step repeats another's index vector
+        if n >= 1_000_000:
+            a, b = allidx[:, 0].ravel().astype(np.float64), allidx[:, 1].ravel().astype(np.float64)
+            assert abs(np.corrcoef(a, b)[0, 1]) < 5 / np.sqrt(a.size)       # neighbouring runs are independent
+    finally:
+        eng.close(); buf.close()
+
+
+def test_cql_prepare_kernel_samples_the_same_rows_for_every_consumer():
+    """k_prepare gathers observation-like sources straight from the dataset for several outputs (batch slots, actor input, critic
+    input rows and their N-fold repeats): all of them must come from the same sampled row (one index per (run, batch row))."""
+    eng, mod, cfg, st, c = _make("cql", "cql_tiny", 2, 0)
+    B, od, ad, N = c["B"], c["obs_dim"], c["act_dim"], c["N"]
+    buf = _buffer(_dataset(2, 5_000, od, ad), od, ad)
+    eng.attach_buffer(buf)
+    try:
+        eng.learn_n(1)
+        for r in range(2):
+            b = _tapped_batch(eng, r, B, od, ad)
+            xc = eng.debug_read(r, "xc").reshape(B + 3 * B * N, -1)
+            assert np.array_equal(xc[:B, :od], b["observations"]) and np.array_equal(xc[:B, od:od + ad], b["actions"])
+            rep = np.repeat(b["observations"], N, axis=0)
+            for j in range(3):
+                assert np.array_equal(xc[B + j * B * N:B + (j + 1) * B * N, :od], rep)       # cql.py:142-151: the critic sees tmp_obs in all three
+    finally:
+        eng.close(); buf.close()
+
+
+def test_reloaded_buffer_is_what_the_next_learn_n_samples():
+    """ReplayBuffer.load_dataset / add_batch after training started (buffer.py:34-86): orl_buffer_load frees and re-allocates the
+    device arrays; graphs captured against the old pointers must not be replayed."""
+    from offlinerlkit import _engine
+    eng, mod, cfg, st, c = _make("cql", "cql_tiny", 2, 0)
+    B, od, ad = c["B"], c["obs_dim"], c["act_dim"]
+    ds = _dataset(3, 4_000, od, ad)
+    buf = _buffer(ds, od, ad)
+    eng.attach_buffer(buf)
+    try:
+        eng.learn_n(3)
+        old_rows = {tuple(np.round(x, 5)) for x in ds["observations"]}
+        assert all(tuple(np.round(x, 5)) in old_rows for x in eng.debug_read(0, "b_obs").reshape(B, od))
+        ds2 = _dataset(4, 9_000, od, ad)                      # different contents AND a different size
+        ds2["observations"] += 100.0
+        buf.load(ds2["observations"], ds2["actions"], ds2["next_observations"], ds2["rewards"], ds2["terminals"])
+        m, _ = eng.learn_n(2)
+        assert np.isfinite(m).all()
+        got = eng.debug_read(0, "b_obs").reshape(B, od)
+        new_rows = {tuple(np.round(x, 4)) for x in ds2["observations"]}
+        assert got.min() > 50.0 and all(tuple(np.round(x, 4)) in new_rows for x in got)
+        assert eng.step_count() == 5
+    finally:
+        eng.close(); buf.close()

@@ -138,3 +138,108 @@ def test_modules_state_dict_keys_match_reference_inventory():
     assert sum(p.numel() for p in e.parameters()) == 2759700
     assert tuple(e.state_dict()["model.0.weight"].shape) == (10, 23, 256) and tuple(e.state_dict()["model.6.bias"].shape) == (10, 1, 1)
     assert "model.2.saved_weight" in e.state_dict()
+
+
+class BatchPolicy(tf.FakePolicy):
+    """select_action on [E, OBS] batches; the action depends on the observation so the env-by-env bookkeeping is visible"""
+
+    def __init__(self):
+        super().__init__()
+        self.calls = []
+
+    def select_action(self, obs, deterministic=False):
+        assert deterministic and obs.ndim == 2 and obs.shape[1] == tf.OBS and self.mode == "eval"
+        self.calls.append(obs.shape[0])
+        return np.repeat(obs[:, :1], tf.ACT, axis=1).astype(np.float32)
+
+
+def _sequential_reference(envs_eps, n_eps):
+    """what the reference's one-env loop (mf_policy_trainer.py:92-118) reports for the same policy on the same episodes"""
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+    pol = BatchPolicy()
+    tr = MFPolicyTrainer(pol, envs_eps, None, None, eval_episodes=n_eps, fused=False)
+    return tr._evaluate(), pol
+
+
+def test_batched_evaluation_keeps_the_reference_episode_accounting():
+    """§8(f)4: E envs in lockstep with one batched forward per step report the episodes the sequential reference loop reports
+    (FakeEnv episode k lasts 3 + k % 2 steps and starts from 0.1 k, so every episode is distinguishable)."""
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+
+    def env_at(ep):
+        e = tf.FakeEnv()
+        e.ep = ep
+        return e
+    n_eps = 6
+    # sequential: ONE env plays episodes 0..5 in a row
+    seq, pol_s = _sequential_reference(env_at(0), n_eps)
+    assert all(c == 1 for c in pol_s.calls)
+    # batched: six envs, env i starts at episode i -> the same six episodes, in lockstep
+    envs = [env_at(i) for i in range(n_eps)]
+    pol_b = BatchPolicy()
+    tr = MFPolicyTrainer(pol_b, envs, None, None, eval_episodes=n_eps, fused=False)
+    bat = tr._evaluate()
+    assert sorted(bat["eval/episode_length"]) == sorted(seq["eval/episode_length"])
+    np.testing.assert_allclose(sorted(bat["eval/episode_reward"]), sorted(seq["eval/episode_reward"]), rtol=1e-6)
+    assert pol_b.calls[0] == n_eps and len(pol_b.calls) == max(seq["eval/episode_length"])     # 4 forwards instead of 21
+    assert sum(pol_b.calls) == sum(seq["eval/episode_length"])
+    # fewer envs than episodes: finished envs are reset and reused until eval_episodes episodes have STARTED
+    envs = [env_at(0), env_at(0)]
+    tr = MFPolicyTrainer(BatchPolicy(), envs, None, None, eval_episodes=5, fused=False)
+    out = tr._evaluate()
+    assert len(out["eval/episode_reward"]) == 5 and envs[0].ep + envs[1].ep == 5
+    # more envs than episodes: only eval_episodes of them run
+    envs = [env_at(i) for i in range(4)]
+    tr = MFPolicyTrainer(BatchPolicy(), envs, None, None, eval_episodes=2, fused=False)
+    out = tr._evaluate()
+    assert len(out["eval/episode_reward"]) == 2 and envs[2].t == 0 and envs[3].t == 0
+
+
+class MultiRunPolicy(tf.FakePolicy):
+    """duck-typed n_runs policy (EnginePolicy's multi-run surface) for the GPU-less container"""
+    n_runs = 3
+
+    def __init__(self):
+        super().__init__()
+        self.cur = 0
+
+    def learn_n(self, n, buffer, batch_size):
+        out = {"loss/a": 2.0}
+        for r in range(self.n_runs):
+            out[f"run{r}/loss/a"] = 1.0 + r
+        return out
+
+    def select_run(self, r):
+        self.cur = r
+
+    def run_state_dict(self, r):
+        return {"w": self.w.detach().clone() + r}
+
+    def select_action(self, obs, deterministic=False):
+        return np.full((1, tf.ACT), 0.25 * (self.cur + 1), dtype=np.float32)
+
+
+def test_trainer_logs_and_checkpoints_every_run_of_a_multi_run_policy(tmp_path):
+    import torch
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+    from offlinerlkit.utils.logger import Logger
+    logger = Logger(str(tmp_path), {"policy_training_progress": "csv"})
+    pol = MultiRunPolicy()
+
+    class Buf:
+        def device_buffer(self):
+            return self
+    tr = MFPolicyTrainer(pol, tf.FakeEnv(), Buf(), logger, epoch=2, step_per_epoch=5, batch_size=8, eval_episodes=2)
+    tr.train()
+    lines = open(tmp_path / "record" / "policy_training_progress.csv").read().strip().split("\n")
+    head = lines[0].split(",")
+    row = dict(zip(head, lines[-1].split(",")))
+    for r in range(3):
+        assert float(row[f"run{r}/loss/a"]) == 1.0 + r
+        assert f"run{r}/eval/episode_reward" in head and f"run{r}/eval/normalized_episode_reward" in head
+        sd = torch.load(tmp_path / "model" / f"policy_run{r}.pth", weights_only=True)
+        assert float(sd["w"][0]) == float(r)
+    # run r's actions are 0.25 (r + 1) per dim: episode reward per step = 1 + 0.5 * ACT * 0.25 (r + 1) -> runs are evaluated separately
+    r0, r2 = float(row["run0/eval/episode_reward"]), float(row["run2/eval/episode_reward"])
+    assert r2 > r0
+    assert float(row["loss/a"]) == 2.0 and pol.cur == 0
