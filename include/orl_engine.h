@@ -197,6 +197,10 @@ int64_t orl_step_count(orl_engine* e);
  * step ("b_obs","b_nobs","b_act","b_rew","b_term": what ReplayBuffer.sample returned / the device sampler drew) and its noise
  * arrays under their orl_noise slot names ("n_eps_actor", ...). */
 int64_t orl_debug_read(orl_engine* e, int run, const char* name, float* host, int64_t cap);
+/* packed ReLU-mask words (bit b of word w of a row <-> unit 32 w + b is > 0) of a hidden-activation workspace of the LAST step,
+ * e.g. "ch0" / "ch1" = the CQL critics' hidden layers: [members][rows][width / 32] words; < 0 when the kernels that ran did not
+ * emit bits for it.  What the backward kernels read instead of the activation (autograd's threshold_backward mask). */
+int64_t orl_debug_read_bits(orl_engine* e, int run, const char* name, uint32_t* host, int64_t cap_words);
 /* gradient of the LAST step w.r.t. the parameters of a trainable net, flat in state_dict order (orl_net_floats values): what
  * autograd leaves in param.grad before optimizer.step() (cql.py:180-190 etc.); the split-K slabs of the backward kernels summed. */
 int orl_debug_grads(orl_engine* e, int run, int net, float* host, int64_t n_floats);

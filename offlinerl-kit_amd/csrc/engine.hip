@@ -1318,6 +1318,21 @@ int64_t orl_debug_read(orl_engine* h, int run, const char* name, float* host, in
   return n;
 }
 
+// packed ReLU-mask words of a hidden activation of the LAST step (one 32-bit word per (row, 32 columns), all members of the family):
+// returns the number of words written, or < 0 (unknown workspace / no mask / the producing launch did not emit bits)
+int64_t orl_debug_read_bits(orl_engine* h, int run, const char* name, uint32_t* host, int64_t cap) {
+  Engine& e = h->e;
+  auto it = e.ws.find(name);
+  if (it == e.ws.end() || !it->second.bits) { fail(std::string("no mask bits for workspace ") + name); return -1; }
+  if (run < 0 || run >= e.R) { fail("bad run"); return -1; }
+  const Mat& m = it->second;
+  if (!e.bits_live.count(m.bits)) { fail(std::string("mask bits of ") + name + " were not emitted by the last step's kernels"); return -1; }
+  if (cap < m.brs) { fail("bits buffer too small"); return -1; }
+  if (hipStreamSynchronize(e.stream) != hipSuccess) { fail("sync"); return -1; }
+  if (hipMemcpy(host, m.bits + (long)run * m.brs, sizeof(uint32_t) * m.brs, hipMemcpyDeviceToHost) != hipSuccess) { fail("bits copy"); return -1; }
+  return m.brs;
+}
+
 // gradient of the LAST step w.r.t. every parameter of `net` (state_dict order, orl_net_floats values): the split-K slabs the
 // backward kernels wrote, summed per tensor group (double accumulation on the host; k_adam sums the same slabs in fp32)
 int orl_debug_grads(orl_engine* h, int run, int net, float* host, int64_t n) {

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
     "orl_set_lr", "orl_reset_optimizers", "orl_adam_get", "orl_adam_set", "orl_set_step_count", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
     "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
-    "orl_debug_read", "orl_debug_grads", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
+    "orl_debug_read", "orl_debug_read_bits", "orl_debug_grads", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
 ]
 
 
@@ -132,6 +132,8 @@ def load_library(path: Optional[str] = None):
     lib.orl_step_count.restype = C.c_int64
     lib.orl_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64]
     lib.orl_debug_read.restype = C.c_int64
+    lib.orl_debug_read_bits.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.orl_debug_read_bits.restype = C.c_int64
     lib.orl_debug_grads.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]
     lib.orl_debug_gemm.argtypes = [C.c_int] * 5 + [C.c_void_p] * 5 + [C.c_int, C.c_int]
     lib.orl_debug_gemm_time.argtypes = [C.c_int] * 8 + [C.POINTER(C.c_float)]
@@ -334,6 +336,14 @@ class Engine:
         n = self.lib.orl_debug_read(self._h, run, name.encode(), buf.ctypes.data, cap)
         if n < 0:
             raise RuntimeError(f"orl_debug_read({name}) failed: {last_error()}")
+        return buf[:n].copy()
+
+    def debug_read_bits(self, run: int, name: str, cap: int = 1 << 24) -> np.ndarray:
+        """packed ReLU-mask words of a hidden-activation workspace (uint32, [members * rows * width/32])"""
+        buf = np.empty(cap, dtype=np.uint32)
+        n = self.lib.orl_debug_read_bits(self._h, run, name.encode(), buf.ctypes.data, cap)
+        if n < 0:
+            raise RuntimeError(f"orl_debug_read_bits({name}) failed: {last_error()}")
         return buf[:n].copy()
 
     def debug_grads(self, run: int, net: int) -> Dict[str, np.ndarray]:

@@ -233,7 +233,7 @@ class EnginePolicy(BasePolicy):
             for nid in nets:
                 self._write_net(r, nid, params[nid])
         self._cur_run = -1
-        self.select_run(0)
+        self.select_run(0, _hook=False)      # (the scalars of the fresh engine are set below: nothing to sync back yet)
         torch.cuda.synchronize(dev)
         self._lr_pushed = {}
         self._push_lrs()
@@ -259,7 +259,7 @@ class EnginePolicy(BasePolicy):
                 raise ValueError(f"{name}: module shape {tuple(src.shape)} != engine shape {tuple(view.shape)}")
             view.copy_(src.to(view.device, dtype=torch.float32))
 
-    def select_run(self, run: int) -> None:
+    def select_run(self, run: int, _hook: bool = True) -> None:
         """Point the torch modules (``state_dict``, ``select_action``, checkpoints) at run ``run``'s live parameters."""
         if self._eng is None:
             if run != 0:
@@ -274,7 +274,8 @@ class EnginePolicy(BasePolicy):
             for name, view in self._net_views(run, nid):
                 params[name].data = view
         self._cur_run = run
-        self._on_select_run(run)
+        if _hook:
+            self._on_select_run(run)
 
     def _on_select_run(self, run: int) -> None:
         pass
