@@ -84,3 +84,22 @@ def test_edac_oracle_matches_reference(case):
         if k in (0, len(batches) - 1):
             check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in ("actor", "critics", "critics_old")}, atol=2e-6 * (k + 1))
             assert abs(float(st["log_alpha"][0]) - float(g[f"state{k}/log_alpha"][0])) < 1e-6
+
+
+@pytest.mark.parametrize("case", list(synth.CQL_CASES))
+def test_torch_cpu_counterpart_of_cql_matches_reference(case):
+    """oracle/torch_cql.py (stock torch autograd + torch.optim.Adam, written against SURVEY Appendix A.1) is bench.py's
+    `cpu_baseline` of kind "port" timed with torch threads: it must reproduce the real reference's losses on the
+    fixtures over the whole teacher-forced window."""
+    import torch
+    from oracle.torch_cql import TorchCQL
+    torch.set_num_threads(4)
+    g = load_golden(case)
+    cfg, st, batches, noises = cql_oracle_setup(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    pol = TorchCQL(st, cfg)
+    for k, (b, n) in enumerate(zip(batches[:6], noises[:6])):
+        res = pol.learn(b, n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 2e-5, (case, k, got, g[f"step{k}/losses"])
