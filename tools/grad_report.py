@@ -9,8 +9,9 @@ from test_gpu_grads import grad_err
 from oracle import cql as ocql
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+CASE = sys.argv[2] if len(sys.argv) > 2 else "cql_halfcheetah"
 for prec in (0, 1):
-    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah", n_runs=R, precision=prec)
+    eng, cfg, st, batches, noises = tc.make_engine(CASE, n_runs=R, precision=prec)
     for k in range(2):
         res, aux = ocql.learn(st, cfg, batches[k], noises[k])
         m = eng.step(tc.lead(batches[k], R), tc.lead(tc.noise_list(noises[k]), R))
