@@ -362,6 +362,10 @@ def main():
     R = args.runs_per_gpu if args.runs_per_gpu is not None else int(os.environ.get("ORL_RUNS_PER_GPU", preset.get("runs_per_gpu", 96)))
     E = max(1, args.engines_per_gpu if args.engines_per_gpu is not None else int(os.environ.get("ORL_ENGINES_PER_GPU", preset.get("engines_per_gpu", 2))))
 
+    if E > 1:
+        # several engines per GPU: each engine's weight-stationary launches stay on CUs / nets workgroups per net (one round), the CUs
+        # they leave idle are where the other engine's kernels run (csrc/ws_gemm.h: ws_blocks_per_problem)
+        os.environ.setdefault("ORL_WS_ONE_ROUND", "1")
     import torch
     dist = None
     backend = os.environ.get("ORL_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 path on one GPU

@@ -60,12 +60,13 @@ def needs_build():
         return fh.read().strip() != source_hash()
 
 
-def _compile(unit, hipcc, verbose):
-    obj, want = _obj(unit), unit_hash(unit)
+def _compile(unit, hipcc, verbose, objdir=None, defines=()):
+    obj = _obj(unit) if objdir is None else os.path.join(objdir, unit.replace(".hip", ".o"))
+    want = unit_hash(unit) + "|" + " ".join(defines)
     stamp = obj + ".srchash"
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return obj
-    cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, unit), "-o", obj]
+    cmd = [hipcc] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, unit), "-o", obj]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
@@ -96,5 +97,22 @@ def build(force=False, verbose=True, jobs=None):
     return LIB
 
 
+def build_variant(name, defines, verbose=False):
+    """Experiment builds: liborlengine_<name>.so compiled with extra -D defines (objects under build/<name>/); select it at run
+    time with ORL_ENGINE_LIB=<path> (offlinerlkit/_engine.py) to A/B two kernels inside ONE gpurun call -- boxes differ by ~10 %."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(OBJ, name)
+    os.makedirs(objdir, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), max(1, (os.cpu_count() or 2) - 1))) as ex:
+        objs = list(ex.map(lambda u: _compile(u, hipcc, verbose, objdir, tuple(defines)), UNITS))
+    lib = os.path.join(HERE, f"liborlengine_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force="--force" in sys.argv)

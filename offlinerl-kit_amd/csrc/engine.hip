@@ -538,6 +538,7 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
   // many batched nets fill the CUs without split-K, but workgroups that all stream thousands of rows from the same offset of
   // equally strided matrices run 2x slower (measured at 256 nets x 7936 rows, fp32: 12.8 -> 5.4 ms): keep >= 4 k-ranges
   if (Krows >= 4096) ks = std::max(ks, long_min);
+  if (cfg == CFG_SQ && Krows < 1024 && kchunks >= 8) ks = std::max(ks, 2);      // 256-row wgrads of many nets: two k-ranges measured 1.5x faster
   ks = std::max(1, std::min(ks, std::min(cap, kchunks)));
   while (ks > 1 && (kchunks + ks - 1) / ks < 2) --ks;
   return ks;
@@ -598,7 +599,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
     w.M = M; w.nz1 = nr.nz1;
     if (ws_wgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab);
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
       prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
                  nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
@@ -773,6 +774,8 @@ int Engine::build_common() {
   alloc("b_obs2", 2 * B, OP);
   alloc("b_act", B, AP); alloc("b_rew", B, 1); alloc("b_term", B, 1);
   alloc("ones", std::max(B, 16), 1);
+  d_idx = (long long*)raw_alloc(sizeof(long long) * (size_t)R * B);
+  if (!d_idx) return fail("hipMalloc minibatch indices");
   taps["b_obs"] = {W("b_obs2"), B, od};
   taps["b_nobs"] = {W("b_obs2").rows(B), B, od};
   taps["b_act"] = {W("b_act"), B, ad};
@@ -885,29 +888,35 @@ void Engine::add_prep(const Mat& dst, int row0, int col0, int rows, int width, i
 int Engine::enqueue_prepare(bool sampling, bool devnoise) {
   PrepP p;
   memset(&p, 0, sizeof(p));
-  long total = 0;
+  int blocks = 0;
   for (auto& s : prep) {
     if (s.need_sampling >= 0 && s.need_sampling != (int)sampling) continue;
     if (s.need_devnoise >= 0 && s.need_devnoise != (int)devnoise) continue;
     if (p.njobs >= 20) return fail("too many prepare jobs");
     PrepJob j = s.job;
-    total += (long)j.rows * j.width;
-    j.elem_end = total;
+    const long n_el = (long)j.rows * j.width;
+    if (n_el > (1L << 30)) return fail("prepare job too large");
+    j.units = (int)((j.src == PS_NORMAL || j.src == PS_UNIFORM) ? (n_el + 3) / 4 : n_el);
+    blocks += (j.units + 255) / 256;
+    j.block_end = blocks;
     p.job[p.njobs++] = j;
   }
   if (p.njobs == 0) return 0;
-  p.total = total;
+  p.blocks = blocks;
   if (sampling) {
     if (!buf || !buf->obs) return fail("no replay buffer attached (orl_engine_attach_buffer)");
     p.d_obs = buf->obs; p.d_nobs = buf->nobs; p.d_act = buf->act; p.d_rew = buf->rew; p.d_term = buf->term; p.n = buf->n;
     p.OP = buf->OP; p.AP = buf->AP;
+    p.idx = d_idx; p.idx_rs = B;
+    ORL_LAUNCH("draw_indices", k_draw_indices, dim3((B + 255) / 256, R), dim3(256), d_idx, (long)B, B, (long)buf->n, (unsigned long long)cfg.seed,
+               (const unsigned long long*)gstep);
   }
   Mat o2 = W("b_obs2");
   p.b_obs = o2.p; p.b_nobs = o2.p + (long)B * OP; p.bo_rs = o2.rs; p.b_op = OP;
   p.b_act = W("b_act").p; p.ba_rs = W("b_act").rs; p.b_ap = AP;
   p.b_rew = W("b_rew").p; p.b_term = W("b_term").p; p.br_rs = W("b_rew").rs;
   p.B = B; p.seed = cfg.seed; p.gstep = gstep; p.lo = cfg.act_low; p.hi = cfg.act_high;
-  ORL_LAUNCH("prepare", k_prepare, dim3((unsigned)((total + 255) / 256), R), dim3(256), p);
+  ORL_LAUNCH("prepare", k_prepare, dim3((unsigned)blocks, R), dim3(256), p);
   return 0;
 }
 

@@ -40,6 +40,31 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+// x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): twelve VALU instructions for four values (two packed
+// conversions per plane, the widening of hi back to fp32 done on the packed words) -- the element-wise form compiled to 20
+__device__ __forceinline__ void orl_split4(const f32x4& v, bf16x4& h, bf16x4& l) {
+  h = __builtin_convertvector(v, bf16x4);
+  const u32x2_t hb = *(const u32x2_t*)&h;
+  f32x4 hf;
+  hf[0] = __uint_as_float(hb[0] << 16); hf[1] = __uint_as_float(hb[0] & 0xffff0000u);
+  hf[2] = __uint_as_float(hb[1] << 16); hf[3] = __uint_as_float(hb[1] & 0xffff0000u);
+  l = __builtin_convertvector(v - hf, bf16x4);
+}
+// bit j = (z[j] > 0): on the fp32 bit patterns read as signed integers, clamp(bits, 0, 1) is 1 exactly for positive non-zero values
+// (v_med3_i32; -0, +0 and negative values give 0) -- 7 instructions instead of 4 compares + 4 selects + 3 ors
+__device__ __forceinline__ unsigned int orl_mask4(const f32x4& z) {
+  unsigned int m = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int b = min(max(__float_as_int(z[j]), 0), 1);
+    m |= (unsigned int)b << j;
+  }
+  return m;
+}
+#endif
+
 // precision of the multiply: P_F32 = v_mfma_f32_16x16x4_f32 (exact fp32);  P_BF16X3 = every operand split into
 // hi = bf16(x), lo = bf16(x - hi) while it is staged into LDS, product = lo*hi + hi*lo + hi*hi on
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per operand, 3/16 of the fp32 MFMA cycles)
@@ -140,6 +165,13 @@ static inline int pick_cfg(int M, int N, int K, int nz) {
   if (N <= 16) return CFG_TALL;
   if (M >= 2048 && N >= 128) return ((long)M * nz >= 40000) ? CFG_SQ : CFG_BIG;   // few rows: 8-wave 64x256 fills the CUs
   if (M <= 32) return CFG_SMALL;
+  // batch-sized products of MANY batched nets (e.g. the 256-row phases of 64+ runs): enough 128 x 128 / 64 x 64 tiles exist to fill the
+  // CUs, and they re-read each operand far less often than the 16 x 64 tiles (256 x 256 x 256, 128 nets: wgrad 108 -> 42 us with two
+  // k-ranges, forward 68 -> 38 us, dgrad 96 -> 47 us; tools/small_gemm_sweep.py)
+  if (K < 1024 && M >= 64 && N >= 64) {
+    if (K >= 256 && M >= 128 && N >= 128 && (long)nz * ((M + 127) / 128) * ((N + 127) / 128) >= 256) return CFG_SQ;
+    if ((long)nz * ((M + 63) / 64) * ((N + 63) / 64) >= 1024) return CFG_MID;
+  }
   // long reductions (wgrad over thousands of rows): square tiles + split-K; batch-sized products: many small workgroups
   if (K >= 1024) return (M >= 256 && N >= 128) ? CFG_WG : ((M >= 128 && N >= 128) ? CFG_SQ : CFG_MID);
   return CFG_SMALL;

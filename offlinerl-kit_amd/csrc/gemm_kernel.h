@@ -163,8 +163,8 @@ struct TileLoader {
 
   // split-bf16 staging: hi plane at lds_h, lo plane ROWS*PITCH elements further
   __device__ static inline void split4(const float* o, bf16x4& h, bf16x4& l) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)o[j]; h[j] = hh; l[j] = (__bf16)(o[j] - (float)hh); }
+    const f32x4 v = {o[0], o[1], o[2], o[3]};
+    orl_split4(v, h, l);
   }
   __device__ inline void store_split(__bf16* __restrict__ lds_h, int tid) const {
     __bf16* lds_l = lds_h + ROWS * PITCH;

@@ -144,13 +144,16 @@ __global__ void k_noise(float* out, long n_per_run, int kind, float lo, float hi
 // ------------------------------------------------------------------------------------------------
 // k_prepare: ONE launch that materialises every input of a step — replay gather (batch slots), critic-input
 // matrices X = (obs | act | 0-pad) with repeated rows, and all noise arrays — instead of 1 gather + N noise +
-// M assemble launches.  A job table (<= 16 entries, passed by value) describes the outputs; one thread per
-// output element.  Observation-like sources are read either straight from the HBM dataset through the Philox
-// (or host-supplied) index of the row (sampling mode) or from the batch slots (teacher-forced mode).
+// M assemble launches.  A job table (<= 20 entries, passed by value) describes the outputs; one thread per
+// output element (four elements for the noise jobs: one Philox4x32 call each).  Observation-like sources are read either
+// straight from the HBM dataset through the step's minibatch indices (sampling mode: k_draw_indices runs first) or from the
+// batch slots (teacher-forced mode).
 // ------------------------------------------------------------------------------------------------
 enum { PS_OBS = 0, PS_NOBS = 1, PS_ACT = 2, PS_REW = 3, PS_TERM = 4, PS_NORMAL = 5, PS_UNIFORM = 6, PS_BUF = 7, PS_ZERO = 8 };
 struct PrepJob {
-  long elem_end;        // exclusive end of this job's element range (per run)
+  int block_end;        // exclusive end of this job's range of 256-thread blocks (per run): a block serves ONE job, so the job lookup
+                        // is a scalar loop; a thread's unit = one element, or four for the noise jobs
+  int units;            // work units of the job
   float* dst; long dst_rs; int dst_pitch, dst_row0, dst_col0;
   int rows, width;      // output region: rows x width
   int src;              // PS_*
@@ -162,48 +165,62 @@ struct PrepJob {
 struct PrepP {
   PrepJob job[20];
   int njobs;
-  long total;           // elements per run
+  int blocks;           // blocks per run
   // dataset (sampling mode) or null -> batch slots
   const float *d_obs, *d_nobs, *d_act, *d_rew, *d_term; long n; int OP, AP;
-  const long long* idx; long idx_rs;
+  const long long* idx; long idx_rs;                  // the minibatch indices of this step [R][B] (k_draw_indices or host-supplied)
   const float *b_obs, *b_nobs, *b_act, *b_rew, *b_term; long bo_rs, ba_rs, br_rs; int b_op, b_ap;
   int B;
   unsigned long long seed; const unsigned long long* gstep; float lo, hi;
 };
+// np.random.randint(0, size, B) (buffer.py:98) on the device: one Philox call per (run, batch row), drawn ONCE per step and shared by
+// every consumer of that row (batch slots, actor / critic input rows and their N-fold repeats)
+__global__ void k_draw_indices(long long* out, long out_rs, int B, long n, unsigned long long seed, const unsigned long long* gstep) {
+  const int r = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const unsigned long long ctr = *gstep;
+  Philox ph(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
+  uint32_t o[4];
+  ph((uint32_t)b, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
+  out[(long)r * out_rs + b] = (long long)(((unsigned long long)o[0] * (unsigned long long)n) >> 32);
+}
 __global__ void k_prepare(PrepP p) {
   const int r = blockIdx.y;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= p.total) return;
   int ji = 0;
-  while (ji < p.njobs - 1 && t >= p.job[ji].elem_end) ++ji;
+  while (ji < p.njobs - 1 && (int)blockIdx.x >= p.job[ji].block_end) ++ji;       // block-uniform: scalar compares
   const PrepJob& jb = p.job[ji];
-  const long e = t - (ji ? p.job[ji - 1].elem_end : 0);
-  const int row = (int)(e / jb.width), col = (int)(e - (long)row * jb.width);
-  float v = 0.f;
-  const unsigned long long ctr = p.gstep ? *p.gstep : 0ull;
+  const int u = ((int)blockIdx.x - (ji ? p.job[ji - 1].block_end : 0)) * 256 + (int)threadIdx.x;
+  if (u >= jb.units) return;
   if (jb.src == PS_NORMAL || jb.src == PS_UNIFORM) {
-    // one Philox call yields 4 values: element e uses lane e&3 of counter e>>2
+    // one Philox call yields the four values of elements 4u .. 4u + 3 of the job
+    const unsigned long long ctr = p.gstep ? *p.gstep : 0ull;
     Philox ph(p.seed);
     uint32_t o[4];
-    ph((uint32_t)(e >> 2), (uint32_t)r | (jb.stream_id << 16), (uint32_t)ctr, 0xA5u ^ (uint32_t)(ctr >> 32), o);
-    if (jb.src == PS_NORMAL) {
-      float n0, n1;
-      if ((e & 2) == 0) box_muller(o[0], o[1], n0, n1); else box_muller(o[2], o[3], n0, n1);
-      v = (e & 1) ? n1 : n0;
-    } else v = p.lo + (p.hi - p.lo) * u01(o[e & 3]);
-  } else if (jb.src == PS_BUF) {
+    ph((uint32_t)u, (uint32_t)r | (jb.stream_id << 16), (uint32_t)ctr, 0xA5u ^ (uint32_t)(ctr >> 32), o);
+    float v[4];
+    if (jb.src == PS_NORMAL) { box_muller(o[0], o[1], v[0], v[1]); box_muller(o[2], o[3], v[2], v[3]); }
+    else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = p.lo + (p.hi - p.lo) * u01(o[k]);
+    }
+    const int n_el = jb.rows * jb.width, e0 = 4 * u;
+    int row = e0 / jb.width, col = e0 - row * jb.width;
+    float* d = jb.dst + (long)r * jb.dst_rs + (long)jb.dst_row0 * jb.dst_pitch + jb.dst_col0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (e0 + k < n_el) d[(long)row * jb.dst_pitch + col] = v[k];
+      if (++col == jb.width) { col = 0; ++row; }
+    }
+    return;
+  }
+  const int row = u / jb.width, col = u - row * jb.width;
+  float v = 0.f;
+  if (jb.src == PS_BUF) {
     if (col < jb.ncopy) v = jb.buf[(long)r * jb.buf_rs + (long)((jb.mod ? row % jb.mod : row) / jb.rep) * jb.buf_pitch + col];
   } else if (jb.src != PS_ZERO && col < jb.ncopy) {
     const int b = (jb.mod ? row % jb.mod : row) / jb.rep;
     if (p.d_obs) {
-      long j;
-      if (p.idx) j = p.idx[(long)r * p.idx_rs + b];
-      else {
-        Philox ph(p.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
-        uint32_t o[4];
-        ph((uint32_t)b, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
-        j = (long)(((unsigned long long)o[0] * (unsigned long long)p.n) >> 32);
-      }
+      const long j = p.idx[(long)r * p.idx_rs + b];
       switch (jb.src) {
         case PS_OBS: v = p.d_obs[j * p.OP + col]; break;
         case PS_NOBS: v = p.d_nobs[j * p.OP + col]; break;

@@ -7,11 +7,11 @@ namespace orl {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const __bf16 ha = (__bf16)a[j]; h[j] = ha; l[j] = (__bf16)(a[j] - (float)ha);
-    const __bf16 hb = (__bf16)b[j]; h[4 + j] = hb; l[4 + j] = (__bf16)(b[j] - (float)hb);
-  }
+  bf16x4 ha, la, hb, lb;
+  orl_split4(a, ha, la);
+  orl_split4(b, hb, lb);
+  h = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+  l = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 }  // namespace orl

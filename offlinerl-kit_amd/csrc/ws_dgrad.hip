@@ -160,6 +160,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         bf16x4 zh, zl;
+        // (element by element: gathering the four values first and splitting them with orl_split4 measured 15 % slower here)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4[s][r] : 0.f;

@@ -85,8 +85,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     for (int i = i0; i < i1; ++i) {
       const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
       bf16x4 h, l;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)st[i][j]; h[j] = hh; l[j] = (__bf16)(st[i][j] - (float)hh); }
+      orl_split4(st[i], h, l);
       // 16-byte chunk c = k / 8 of row r lives at chunk c ^ (r & 15): ds_read_b128 of a fragment column is then conflict-free
       // for the hardware's 16-lane groups (which mix lanes of two neighbouring chunks), and these 8-byte stores stay so too
       const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
@@ -132,13 +131,12 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
     *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
     bf16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const __bf16 hh = (__bf16)v[j]; h[j] = hh; l[j] = (__bf16)(v[j] - (float)hh); }
+    orl_split4(v, h, l);
     const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
     *(bf16x4*)(dh + o) = h;
     *(bf16x4*)(dl + o) = l;
     nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
-        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+        (unsigned char)orl_mask4(v);
   };
   auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
 #pragma unroll
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     part += (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
     // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
     nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
-        (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
+        (unsigned char)orl_mask4(v);
   };
   auto epi_row = [&](int par, int s, float part) __attribute__((always_inline)) {
     if (TQ) {
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
   f32x4 pacc[WS_SUB][WS_CB];
   // steady = true: groups g + gs .. g + 3 gs exist, so the body has no conditionals (one basic block up to the barrier)
-  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady) __attribute__((always_inline)) {
+  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady, bool lead = false) __attribute__((always_inline)) {
     const int buf = it & 1;
     const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
     const __bf16* al = ah + WS_ROWS * WS_PITCH;
@@ -266,10 +264,37 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     const bool fine = steady && !DG;
     float fpart = 0.f;
     bf16x8 fxah, fxal;
+    // Steady state: the work of the other pipeline stages is cut into eight pieces, one per k step, and fenced together with that
+    // step's 12 MFMAs -- the default scheduler otherwise clusters all 96 MFMAs and the matrix pipe idles during the epilogue /
+    // staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue; 4..7: the four blocks of the next
+    // group's first layer (or the four staging pieces of the plain variant).
+    auto piece = [&](int ks) __attribute__((always_inline)) {
+      static_assert(WS_SUB == 2 && WS_CB == 2 && WS_LD == 4, "eight pieces");
+      const int par = (it - 1) & 1;
+      if (ks < 4) {
+        const int s = ks >> 1, cb = ks & 1;
+        if (cb == 0) fpart = 0.f;
+        epi_block(pacc[s][cb], g - gs, par, s, cb, fpart);
+        if (cb == 1) epi_row(par, s, fpart);
+      } else if (L0) {
+        const int s = (ks - 4) >> 1, cb = (ks - 4) & 1;
+        if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxal);
+        prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxal);
+      } else {
+        store_group(buf ^ 1, stn, ks - 4, ks - 3);
+        load_piece(g + 2 * gs, stn, ks - 4);
+      }
+    };
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
+      // `lead` (the second wave of each SIMD, waves 4..7): the piece runs BEFORE the step's MFMAs instead of behind them.  The two
+      // waves of a SIMD execute the same program between the same barriers; in step their MFMA bursts collide on the one matrix
+      // pipe and their VALU pieces on the one vector ALU, and the pipe idles half the time (PMC: 50 % busy).  Out of step, one
+      // wave's vector work runs under the other's matrix work.
+      if (fine && lead) { piece(ks); __builtin_amdgcn_sched_barrier(0); }
       // the three products of a block are issued plane by plane (lo*hi, hi*lo, hi*hi over all four blocks) so that dependent MFMAs
       // on one accumulator are four instructions apart; operands swapped: D[n][m], lane holds C[m = li][n = 4 lq + r]
+      // (fetching the fragments one k step ahead, behind the MFMAs that free their registers, measured no different: r02 A/B)
       bf16x8 fah2[WS_SUB], fal2[WS_SUB];
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
@@ -289,25 +314,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
         for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
       if (fine) {
-        // Steady state: the work of the other pipeline stages is cut into eight pieces, one per k step, and fenced together
-        // with that step's 12 MFMAs -- the default scheduler otherwise clusters all 96 MFMAs and the matrix pipe idles during
-        // the epilogue / staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue;
-        // 4..7: the four blocks of the next group's first layer (or the four staging pieces of the plain variant).
-        static_assert(WS_SUB == 2 && WS_CB == 2 && WS_LD == 4, "eight pieces");
-        const int par = (it - 1) & 1;
-        if (ks < 4) {
-          const int s = ks >> 1, cb = ks & 1;
-          if (cb == 0) fpart = 0.f;
-          epi_block(pacc[s][cb], g - gs, par, s, cb, fpart);
-          if (cb == 1) epi_row(par, s, fpart);
-        } else if (L0) {
-          const int s = (ks - 4) >> 1, cb = (ks - 4) & 1;
-          if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxal);
-          prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxal);
-        } else {
-          store_group(buf ^ 1, stn, ks - 4, ks - 3);
-          load_piece(g + 2 * gs, stn, ks - 4);
-        }
+        if (!lead) piece(ks);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -336,8 +343,14 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   int g = g0, it = 0;
   iteration(g, it, st0, true, false);
   g += gs; ++it;
+#ifdef ORL_WS_STAGGER
+  const bool second_half = __builtin_amdgcn_readfirstlane(wave) >= WS_NW / 2;       // wave w and w + 4 share a SIMD
+#else
+  const bool second_half = false;
+#endif
   while (g + 3 * gs < p.groups) {
-    iteration(g, it, st0, false, true);
+    if (second_half) iteration(g, it, st0, false, true, true);
+    else iteration(g, it, st0, false, true, false);
     g += gs; ++it;
   }
   while (g < p.groups) {
@@ -352,11 +365,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
 hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
-  // one workgroup per CU (register-resident weights): spread the 256 CUs over the nz problems, never more workgroups than CUs
-  // (a second partial round of workgroups would double the launch time)
-  int per_z = ws_cu_budget() / nz;
-  if (per_z < 1) per_z = 1;
-  if (per_z > p.groups) per_z = p.groups;
+  // one workgroup per CU (register-resident weights): whole rounds of 256 workgroups over the nz problems (ws_blocks_per_problem)
+  const int per_z = ws_blocks_per_problem(p.groups, nz, 10, 1 << 20);
   const bool l0 = p.X0 != nullptr;
   const size_t lds = ws_fwd_lds_bytes(l0);
   static const hipError_t attr_err = [] {       // thread-safe one-time initialisation (engines may launch from several host threads)

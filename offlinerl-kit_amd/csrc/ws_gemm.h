@@ -70,6 +70,32 @@ static inline int ws_cu_budget() {
   return v;
 }
 
+// Workgroups per problem (net).  One workgroup occupies a CU (512 threads x 256 VGPRs), so a launch runs in ROUNDS of 256 workgroups.
+// With `nz` problems of `groups` row groups each, `per_z` workgroups per problem take ceil(nz * per_z / CUs) rounds of
+// (prologue + ceil(groups / per_z)) group-times.  The old rule (CUs / nz workgroups, one round) left 64 of the 256 CUs idle at 192 problems
+// (96 runs x 2 critics); four workgroups per problem fill three full rounds instead (-16 % by this model: 3 x (10 + 62) against 258).
+// `prologue` = the per-workgroup fixed cost in units of one row group (resident-operand load + pipeline fill: ~10 for the forward /
+// dgrad kernels; the output-stationary wgrad passes a prohibitive value: its per-workgroup slab write and derived tail gradients cost what
+// the idle CUs cost).  Measured, one engine x 96 runs: forward 772 -> 622 us, dgrad 520 -> 439 us, 39.3k -> 41.7k steps/s.
+// ORL_WS_ONE_ROUND=1 restores the old rule: with TWO engines per GPU the idle CUs of one engine's launch are where the other engine's
+// kernels run, and filling them costs more than it gains (2 x 96 runs: 48.0k one round, 44.3k whole rounds) -- bench.py sets it then.
+static inline int ws_blocks_per_problem(int groups, int nz, int prologue, int cap) {
+  const int cus = ws_cu_budget();
+  static const bool one_round = [] { const char* f = getenv("ORL_WS_ONE_ROUND"); return f && atoi(f) != 0; }();
+  int base = cus / nz;
+  if (base < 1) base = 1;
+  if (base > groups) base = groups;
+  if (base > cap) base = cap;
+  if (one_round) return base;
+  int best = base;
+  long best_cost = (long)((nz * (long)base + cus - 1) / cus) * (prologue + (groups + base - 1) / base);
+  for (int pz = base + 1; pz <= 4 * base + 4 && pz <= groups && pz <= cap; ++pz) {
+    const long cost = (long)((nz * (long)pz + cus - 1) / cus) * (prologue + (groups + pz - 1) / pz);
+    if (cost < best_cost) { best_cost = cost; best = pz; }
+  }
+  return best;
+}
+
 static inline bool ws_fwd_supported(const WsFwdP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || (!p.mb && !p.dmask)) return false;
   if (!aligned16(p.X) || (p.x_pitch & 3) || (p.x_s0 & 3) || (p.x_s1 & 3)) return false;
@@ -129,12 +155,8 @@ static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
   return true;
 }
 // blocks per problem (= split-K slabs written per problem)
-static inline int ws_dgrad_blocks(int M, int nz, int max_slab) {
-  const int groups = M / WS_ROWS;
-  int per_z = ws_cu_budget() / nz;
-  if (per_z > groups) per_z = groups;
-  if (per_z > max_slab) per_z = max_slab;
-  return per_z < 1 ? 1 : per_z;
+static inline int ws_dgrad_blocks(int M, int nz, int max_slab, int prologue = 10) {
+  return ws_blocks_per_problem(M / WS_ROWS, nz, prologue, max_slab);
 }
 hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st);      // ws_dgrad.hip
 

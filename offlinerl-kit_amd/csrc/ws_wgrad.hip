@@ -85,11 +85,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     __bf16* gl = gh + WW_IMG;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
     bf16x4 h, l;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gv = s0[i][j] * sdq[i];
-      const __bf16 hh = (__bf16)gv; h[j] = hh; l[j] = (__bf16)(gv - (float)hh);
-    }
+    orl_split4(s0[i] * sdq[i], h, l);
     const int o = ww_off(r, kq >> 1, kq & 1);
     *(bf16x4*)(gh + o) = h;
     *(bf16x4*)(gl + o) = l;

@@ -75,7 +75,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("ORL_ENGINE_LIB") or LIB_PATH       # ORL_ENGINE_LIB: an experiment build (build.py --variant)
     if not os.path.exists(p):
         raise RuntimeError(f"native update engine not built: {p} is missing "
                            f"(run `python offlinerl-kit_amd/build.py` or __graft_entry__.build())")
