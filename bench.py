@@ -439,6 +439,7 @@ def main():
         sides = world == 1 and not args.no_sides
         by_runs, fp32, others = None, None, None
         if sides:
+            os.environ["ORL_WS_ONE_ROUND"] = "0"          # the side engines run alone on the GPU: whole rounds of workgroups
             by_runs = []
             for r_side in (1, 8, 32, 96):
                 es = make_cql_engines(1, r_side, local_rank, args.precision, 100 + r_side, buf)
@@ -450,6 +451,8 @@ def main():
                 es[0].close()
             by_runs.append(dict(runs_per_gpu=R * E, engines_per_gpu=E, value=value, ms_per_step=dt_med / args.steps * 1e3))
             if args.precision != 0:
+                if E > 1:
+                    os.environ["ORL_WS_ONE_ROUND"] = "1"
                 es = make_cql_engines(E, R, local_rank, 0, 7, buf)
                 learn_all(es, 10)
                 n32 = 20
@@ -462,6 +465,7 @@ def main():
                             reps_s=rr, seconds_timed=float(np.sum(rr)), engines_per_gpu=E, runs_per_engine=R, roofline=r32)
                 for g in es:
                     g.close()
+            os.environ["ORL_WS_ONE_ROUND"] = "0"
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("iql", "edac")}
         cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {

@@ -81,7 +81,8 @@ static inline int ws_cu_budget() {
 // kernels run, and filling them costs more than it gains (2 x 96 runs: 48.0k one round, 44.3k whole rounds) -- bench.py sets it then.
 static inline int ws_blocks_per_problem(int groups, int nz, int prologue, int cap) {
   const int cus = ws_cu_budget();
-  static const bool one_round = [] { const char* f = getenv("ORL_WS_ONE_ROUND"); return f && atoi(f) != 0; }();
+  const char* f = getenv("ORL_WS_ONE_ROUND");          // read per launch decision (graph capture time), so a process can hold engines of both kinds
+  const bool one_round = f && atoi(f) != 0;
   int base = cus / nz;
   if (base < 1) base = 1;
   if (base > groups) base = groups;
