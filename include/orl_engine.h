@@ -36,6 +36,7 @@ extern "C" {
 #define ORL_ALGO_IQL 1   /* policy/model_free/iql.py:86-139   */
 #define ORL_ALGO_TD3BC 2 /* policy/model_free/td3bc.py:83-124 */
 #define ORL_ALGO_EDAC 3  /* policy/model_free/edac.py:88-166  */
+#define ORL_ALGO_SAC 4   /* policy/model_free/sac.py:88-140 (MOPOPolicy.learn on the real+model batch, model_based/mopo.py:81-84) */
 
 #define ORL_MAX_HIDDEN 4
 #define ORL_MAX_METRICS 8
@@ -101,6 +102,10 @@ typedef struct orl_config {
   /* EDAC (edac.py:15-52) */
   int32_t num_critics;
   float eta;
+  /* COMBO (policy/model_based/combo.py:110-241): the CQL update on a batch whose first `cql_real_rows` rows are real data and the rest
+   * model rollouts.  The conservative term repeats rows [cql_cons_row0, cql_cons_row0 + cql_cons_rows) ("model": the model part,
+   * "mix": the whole batch) and its -w mean Q term runs over the real rows only.  0 = the whole batch (plain CQL). */
+  int32_t cql_cons_row0, cql_cons_rows, cql_real_rows;
   /* optional caller-owned parameter arena (device pointer, orl_arena_floats()
    * floats) so that framework tensors can alias engine parameters; NULL = the
    * engine allocates with hipMalloc. */
@@ -121,7 +126,7 @@ typedef struct orl_batch {
 /* Explicit noise for a teacher-forced step, in the reference's draw order.
  * CQL: [0] eps_actor (B,A) N(0,1); [1] eps_next (B,A) or (B*N,A) with
  * max_q_backup; [2] u_rand (B*N,A) U[low,high); [3] eps_pi (B*N,A); [4] eps_next_pi (B*N,A).
- * EDAC: [0] eps_actor, [1] eps_next.  TD3BC: [0] eps_target (B,A).  IQL: none.
+ * EDAC: [0] eps_actor, [1] eps_next.  TD3BC: [0] eps_target (B,A).  IQL: none.  SAC: [0] eps_next, [1] eps_actor (B,A).
  * Each array has a leading n_runs dimension. */
 typedef struct orl_noise {
   const float* slot[ORL_MAX_NOISE];

@@ -138,7 +138,7 @@ struct Engine {
   struct PrepSpec { PrepJob job; int need_sampling; int need_devnoise; };   // -1 any, 0 no, 1 yes
   std::vector<PrepSpec> prep;
   void add_prep(const Mat& dst, int row0, int col0, int rows, int width, int src, int rep, int mod, int ncopy, const Mat* buf,
-                unsigned stream_id, int need_sampling, int need_devnoise);
+                unsigned stream_id, int need_sampling, int need_devnoise, int src_row0 = 0);
   int enqueue_prepare(bool sampling, bool devnoise);
   bool prof_on = false;
   std::vector<ProfEntry> prof;
@@ -188,6 +188,7 @@ struct Engine {
   int iql_build(); int iql_step();
   int td3bc_build(); int td3bc_step(bool actor_step);
   int edac_build(); int edac_step();
+  int sac_build(); int sac_step();
 };
 
 }  // namespace orl

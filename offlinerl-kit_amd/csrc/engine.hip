@@ -116,7 +116,7 @@ static int build_layouts(const orl_config& c, NetLayout* lay, long* net_off, boo
   long o = 0, t = 0;
   auto train = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = o; o += l.stride(); };
   auto target = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = t; is_tgt[id] = true; t += l.stride(); };
-  if (c.algo == ORL_ALGO_CQL) {
+  if (c.algo == ORL_ALGO_CQL || c.algo == ORL_ALGO_SAC) {
     train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_TANH_GAUSS, ad));
     train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
     target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
@@ -763,6 +763,7 @@ static SampleJob make_job(int head_row0, int rows, int rep, const Mat& eps, cons
 #include "algo_iql.inc"
 #include "algo_td3bc.inc"
 #include "algo_edac.inc"
+#include "algo_sac.inc"
 
 namespace orl {
 
@@ -784,6 +785,10 @@ int Engine::build_common() {
   // column-tile partial sums of fused single-output tails (linear_fwd): up to 3 extra parts of the longest row batch
   tq_scratch_nets = std::max(2, K);
   alloc("tq_scratch", 3L * (B + 3L * B * N), 1, tq_scratch_nets);
+  if (cfg.algo == ORL_ALGO_CQL) {
+    if (cfg.cql_cons_row0 < 0 || cfg.cql_cons_rows < 0 || cfg.cql_real_rows < 0 || cfg.cql_cons_row0 + cfg.cql_cons_rows > B || cfg.cql_real_rows > B)
+      return fail("cql_cons_row0 / cql_cons_rows / cql_real_rows out of the batch");
+  }
   return 0;
 }
 
@@ -832,6 +837,7 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_IQL: rc = iql_build(); break;
     case ORL_ALGO_TD3BC: rc = td3bc_build(); break;
     case ORL_ALGO_EDAC: rc = edac_build(); break;
+    case ORL_ALGO_SAC: rc = sac_build(); break;
   }
   if (rc) return rc;
   for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ad};      // the noise arrays of the last step
@@ -874,13 +880,13 @@ int Engine::enqueue_noise() {
 }
 
 void Engine::add_prep(const Mat& dst, int row0, int col0, int rows, int width, int src, int rep, int mod, int ncopy, const Mat* buf,
-                      unsigned stream_id, int need_sampling, int need_devnoise) {
+                      unsigned stream_id, int need_sampling, int need_devnoise, int src_row0) {
   PrepSpec s;
   memset(&s, 0, sizeof(s));
   s.job.dst = dst.p; s.job.dst_rs = dst.rs; s.job.dst_pitch = dst.pitch; s.job.dst_row0 = row0; s.job.dst_col0 = col0;
   s.job.rows = rows; s.job.width = width; s.job.src = src; s.job.rep = rep; s.job.mod = mod; s.job.ncopy = ncopy;
   if (buf) { s.job.buf = buf->p; s.job.buf_rs = buf->rs; s.job.buf_pitch = buf->pitch; }
-  s.job.stream_id = stream_id;
+  s.job.stream_id = stream_id; s.job.src_row0 = src_row0;
   s.need_sampling = need_sampling; s.need_devnoise = need_devnoise;
   prep.push_back(s);
 }
@@ -934,6 +940,7 @@ int Engine::enqueue_step(int variant) {
     case ORL_ALGO_IQL: rc = iql_step(); break;
     case ORL_ALGO_TD3BC: rc = td3bc_step(variant == 1); break;
     case ORL_ALGO_EDAC: rc = edac_step(); break;
+    case ORL_ALGO_SAC: rc = sac_step(); break;
   }
   if (rc) return rc;
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, stream, gstep);
@@ -976,6 +983,7 @@ void orl_config_default(orl_config* c, int32_t algo) {
   c->num_critics = 10; c->eta = 1.0f;
   if (algo == ORL_ALGO_IQL || algo == ORL_ALGO_TD3BC) { c->actor_lr = 3e-4f; }
   if (algo == ORL_ALGO_EDAC) { c->n_hidden = 3; c->hidden[2] = 256; c->deterministic_backup = 0; }
+  if (algo == ORL_ALGO_SAC) { c->actor_lr = 1e-4f; c->critic_lr = 3e-4f; c->deterministic_backup = 0; }   /* run_mopo.py:33-34 */
 }
 
 int64_t orl_arena_floats(const orl_config* cfg) {

@@ -157,7 +157,8 @@ struct PrepJob {
   float* dst; long dst_rs; int dst_pitch, dst_row0, dst_col0;
   int rows, width;      // output region: rows x width
   int src;              // PS_*
-  int rep, mod;         // source row = (mod ? row % mod : row) / rep
+  int rep, mod;         // source row = src_row0 + (mod ? row % mod : row) / rep
+  int src_row0;
   int ncopy;            // columns [0, ncopy) come from the source, the rest of `width` is zero
   const float* buf; long buf_rs; int buf_pitch;   // PS_BUF source
   unsigned stream_id;   // noise stream
@@ -216,9 +217,9 @@ __global__ void k_prepare(PrepP p) {
   const int row = u / jb.width, col = u - row * jb.width;
   float v = 0.f;
   if (jb.src == PS_BUF) {
-    if (col < jb.ncopy) v = jb.buf[(long)r * jb.buf_rs + (long)((jb.mod ? row % jb.mod : row) / jb.rep) * jb.buf_pitch + col];
+    if (col < jb.ncopy) v = jb.buf[(long)r * jb.buf_rs + (long)(jb.src_row0 + (jb.mod ? row % jb.mod : row) / jb.rep) * jb.buf_pitch + col];
   } else if (jb.src != PS_ZERO && col < jb.ncopy) {
-    const int b = (jb.mod ? row % jb.mod : row) / jb.rep;
+    const int b = jb.src_row0 + (jb.mod ? row % jb.mod : row) / jb.rep;
     if (p.d_obs) {
       const long j = p.idx[(long)r * p.idx_rs + b];
       switch (jb.src) {
@@ -443,6 +444,7 @@ struct CqlLossP {
   float* target_q; long tq_rs;             // [R][B] (tap)
   float* part; int nblk;                   // partial sums [R][2][nblk][3] = (s_td, s_q, s_lse)
   int B, N, A;
+  int Bc, Br;                              // COMBO: conservative rows repeat Bc batch rows; the -w mean Q term runs over the first Br rows
   float gamma, w, T, thr;
   int max_q_backup, det_backup, with_lagrange, auto_alpha; float fixed_alpha;
   RunScalars* sc; const Hyper* hy; float b1, b2, eps;
@@ -454,7 +456,7 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
   __shared__ float sh[4];
   const int blk = blockIdx.x, c = blockIdx.y, r = blockIdx.z;
   const RunScalars& sc = p.sc[r];
-  const int B = p.B, BN = p.B * p.N;
+  const int B = p.B, BN = p.Bc * p.N;
   const float alpha = p.auto_alpha ? sc.alpha : p.fixed_alpha;
   float cs = 1.0f;
   if (p.with_lagrange) cs = fminf(fmaxf(expf(sc.cql_log_alpha), 0.f), 1e6f);
@@ -478,8 +480,9 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
       const float y = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
       if (c == 0) p.target_q[(long)r * p.tq_rs + b] = y;
       const float d = q[b] - y;
-      s_td += d * d; s_q += q[b];
-      dq[b] = 2.0f * d / (float)B - cs * p.w / (float)B;
+      s_td += d * d;
+      if (b < p.Br) s_q += q[b];
+      dq[b] = 2.0f * d / (float)B - (b < p.Br ? cs * p.w / (float)p.Br : 0.f);
     }
   }
   const float* lpp = p.logp_pi + (long)r * p.lpp_rs;
@@ -507,7 +510,7 @@ __global__ void k_cql_loss_fin(CqlLossP p) {
   const int r = blockIdx.x;
   if (threadIdx.x != 0) return;
   RunScalars& sc = p.sc[r];
-  const int B = p.B, BN = p.B * p.N;
+  const int B = p.B, BN = p.Bc * p.N;
   float cs = 1.0f, e_cla = 0.f;
   if (p.with_lagrange) { e_cla = expf(sc.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
   float raw[2];
@@ -515,7 +518,7 @@ __global__ void k_cql_loss_fin(CqlLossP p) {
     float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
     const float* o = p.part + ((long)r * 2 + c) * p.nblk * 3;
     for (int k = 0; k < p.nblk; ++k) { s_td += o[k * 3]; s_q += o[k * 3 + 1]; s_lse += o[k * 3 + 2]; }
-    float cons = (s_lse / (float)BN) * p.w * p.T - (s_q / (float)B) * p.w;
+    float cons = (s_lse / (float)BN) * p.w * p.T - (s_q / (float)p.Br) * p.w;
     raw[c] = cons - p.thr;
     if (p.with_lagrange) cons = cs * raw[c];
     const float loss = s_td / (float)B + cons;

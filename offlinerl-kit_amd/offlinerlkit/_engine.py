@@ -15,8 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "liborlengine.so")
 
-ALGO_CQL, ALGO_IQL, ALGO_TD3BC, ALGO_EDAC = 0, 1, 2, 3
-ALGO_ID = {"cql": ALGO_CQL, "iql": ALGO_IQL, "td3bc": ALGO_TD3BC, "edac": ALGO_EDAC}
+ALGO_CQL, ALGO_IQL, ALGO_TD3BC, ALGO_EDAC, ALGO_SAC = 0, 1, 2, 3, 4
+ALGO_ID = {"cql": ALGO_CQL, "iql": ALGO_IQL, "td3bc": ALGO_TD3BC, "edac": ALGO_EDAC, "sac": ALGO_SAC}
 MAX_HIDDEN, MAX_METRICS, MAX_NOISE = 4, 8, 6
 NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC1_OLD, NET_CRITIC2_OLD, NET_CRITIC_V, NET_ACTOR_OLD = range(7)
 NUM_NETS = 7
@@ -54,6 +54,7 @@ class OrlConfig(C.Structure):
         ("policy_noise", C.c_float), ("noise_clip", C.c_float), ("td3bc_alpha", C.c_float), ("max_action", C.c_float),
         ("update_actor_freq", C.c_int32),
         ("num_critics", C.c_int32), ("eta", C.c_float),
+        ("cql_cons_row0", C.c_int32), ("cql_cons_rows", C.c_int32), ("cql_real_rows", C.c_int32),
         ("external_arena", C.c_void_p),
     ]
 

@@ -183,10 +183,16 @@ class EnginePolicy(BasePolicy):
 
     _TARGET_OF = {_engine.NET_CRITIC1_OLD: _engine.NET_CRITIC1, _engine.NET_CRITIC2_OLD: _engine.NET_CRITIC2, _engine.NET_ACTOR_OLD: _engine.NET_ACTOR}
 
+    def _rebind_with(self, carried, batch_size: int) -> None:
+        """bind a fresh engine around state taken from ``_unbind()`` (subclasses whose row layout changed)"""
+        self._carried = carried
+        self._bind(batch_size)
+
     def _bind(self, batch_size: int) -> None:
         if self._eng is not None and self._bound_batch == batch_size:
             return
-        carried = None
+        carried = getattr(self, "_carried", None)
+        self._carried = None
         if self._eng is not None:        # batch size changed: rebuild around the current weights AND optimizer state
             carried = self._unbind()
         dev = self._device()

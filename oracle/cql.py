@@ -54,6 +54,11 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
     B = obs.shape[0]
     N = cfg["num_repeat_actions"]
     A = act.shape[1]
+    # COMBOPolicy.learn (policy/model_based/combo.py:110-241) = this update on the concatenated real + model batch, with the
+    # conservative term's repeated rows taken from rows [c0, c0 + Bc) ("model": the model part, "mix": everything, combo.py:168-171)
+    # and its data term -w mean Q from the first Br (real) rows only (:198-199)
+    c0, Bc = cfg.get("cons_rows", (0, B))
+    Br = cfg.get("real_rows", B)
     actor, c1, c2 = state["actor"], state["critic1"], state["critic2"]
     c1o, c2o = state["critic1_old"], state["critic2_old"]
     aux = {}
@@ -109,8 +114,8 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
     td2 = f32(((q2 - target_q) ** 2).mean(dtype=f32))
 
     # ---- conservative term (cql.py:137-168) ---------------------------------
-    tmp_obs = np.repeat(obs, N, axis=0)              # row b*N+n  (cql.py:142-144)
-    tmp_nobs = np.repeat(nobs, N, axis=0)
+    tmp_obs = np.repeat(obs[c0:c0 + Bc], N, axis=0)              # row b*N+n  (cql.py:142-144)
+    tmp_nobs = np.repeat(nobs[c0:c0 + Bc], N, axis=0)
     a_pi, lp_pi, _ = nn.tanh_gauss_fwd(actor, tmp_obs, noise["eps_pi"])
     a_npi, lp_npi, _ = nn.tanh_gauss_fwd(actor, tmp_nobs, noise["eps_next_pi"])
     u_rand = np.asarray(noise["u_rand"], f32)
@@ -129,7 +134,7 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
         se = ez.sum(axis=1, keepdims=True, dtype=f32)
         lse = (np.log(se) + zmax).astype(f32)
         soft = (ez / se).astype(f32)
-        cons = f32(lse.mean(dtype=f32) * w * T - q.mean(dtype=f32) * w)
+        cons = f32(lse.mean(dtype=f32) * w * T - q[:Br].mean(dtype=f32) * w)
         crit.append(dict(c=c, q=q, hq=hq, hp=hp, hn=hn, hr=hr, soft=soft, cons=cons, cat=cat))
     aux["cat_q1"], aux["cat_q2"] = crit[0]["cat"], crit[1]["cat"]
 
@@ -148,12 +153,13 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise: Dict[str,
         cons_scale = cql_alpha                        # critics use the pre-step value (cql.py:170-178)
 
     # ---- critic updates (cql.py:180-190) ------------------------------------
-    BN = B * N
+    BN = Bc * N
+    real = (np.arange(B) < Br).astype(f32).reshape(-1, 1)
     losses = []
     for name, cr, td in (("critic1", crit[0], td1), ("critic2", crit[1], td2)):
         c, q = cr["c"], cr["q"]
         losses.append(f32(td + cr["cons"]))
-        dq = (f32(2.0) * (q - target_q) / f32(B) - cons_scale * w / f32(B)).astype(f32)
+        dq = (f32(2.0) * (q - target_q) / f32(B) - real * (cons_scale * w / f32(Br))).astype(f32)
         dv = (cons_scale * w / f32(BN)) * cr["soft"]          # (BN,3); dv/dq = 1
         grads = None
         for hs, d in ((cr["hq"], dq), (cr["hp"], dv[:, 0:1]), (cr["hn"], dv[:, 1:2]), (cr["hr"], dv[:, 2:3])):

@@ -279,3 +279,88 @@ def edac_case_inputs(case):
     batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
     noises = [make_sac_noise(rng, c["B"], ad, rows_next=(10 * c["B"] if mq else None)) for _ in range(c["steps"])]
     return c, st, batches, noises
+
+
+# ----------------------------------------------------------------------------
+# model-based callers of the path: MOPO = SAC.learn, COMBO = CQL.learn variant, both on a real + model batch
+# ----------------------------------------------------------------------------
+MOPO_CASES = {
+    # real_ratio 0.05 of batch 256 (run_mopo.py:60-61): 12 real + 244 model rows
+    "mopo_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B_real=4, B_fake=12, steps=5, seed=501, over={}),
+    "mopo_tiny_fixed_alpha": dict(obs_dim=4, act_dim=2, hidden=[32, 32], B_real=3, B_fake=5, steps=3, seed=502, over=dict(auto_alpha=False, alpha=0.2)),
+    "mopo_halfcheetah": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B_real=12, B_fake=244, steps=5, seed=51, over={}),
+}
+COMBO_CASES = {
+    "combo_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B_real=8, B_fake=8, N=3, steps=5, seed=601, over=dict(rho_s="mix")),
+    "combo_tiny_model": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B_real=6, B_fake=10, N=3, steps=3, seed=602, over=dict(rho_s="model")),
+    "combo_tiny_lagrange": dict(obs_dim=4, act_dim=2, hidden=[32, 32], B_real=8, B_fake=8, N=3, steps=3, seed=603,
+                                over=dict(rho_s="model", with_lagrange=True)),
+    # run_combo.py: batch 256, real_ratio 0.5, hidden [256,256,256], rho_s mix
+    "combo_halfcheetah": dict(obs_dim=17, act_dim=6, hidden=[256, 256, 256], B_real=128, B_fake=128, N=10, steps=3, seed=61, over=dict(rho_s="mix")),
+}
+
+
+def _split_batch(rng, c):
+    real = make_batch(rng, c["B_real"], c["obs_dim"], c["act_dim"])
+    fake = make_batch(rng, c["B_fake"], c["obs_dim"], c["act_dim"])
+    return OrderedDict(real=real, fake=fake)
+
+
+def mix_batch(b):
+    """real rows first, then model rows (torch.cat([real, fake], 0), mopo.py:83 / combo.py:113)"""
+    return OrderedDict((k, np.concatenate([b["real"][k], b["fake"][k]], axis=0)) for k in b["real"])
+
+
+def _sac_like_state(rng, c):
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    state = OrderedDict()
+    state["actor"] = make_tanh_actor(rng, od, ad, hid)
+    state["critic1"] = make_critic(rng, od + ad, hid)
+    state["critic2"] = make_critic(rng, od + ad, hid)
+    for k in ("critic1", "critic2"):
+        state[k + "_old"] = _perturbed(rng, state[k])
+    state["log_alpha"] = np.array([-0.3], dtype=f32)
+    return state
+
+
+def mopo_case_inputs(case):
+    c = MOPO_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    state = _sac_like_state(rng, c)
+    B = c["B_real"] + c["B_fake"]
+    batches = [_split_batch(rng, c) for _ in range(c["steps"])]
+    noises = [OrderedDict(eps_next=rng.standard_normal((B, c["act_dim"])).astype(f32),
+                          eps_actor=rng.standard_normal((B, c["act_dim"])).astype(f32)) for _ in range(c["steps"])]
+    return c, state, batches, noises
+
+
+def combo_case_inputs(case):
+    c = COMBO_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    state = _sac_like_state(rng, c)
+    state["cql_log_alpha"] = np.array([0.2], dtype=f32)
+    B = c["B_real"] + c["B_fake"]
+    Bc = c["B_fake"] if c["over"].get("rho_s") == "model" else B
+    A, N = c["act_dim"], c["N"]
+    batches = [_split_batch(rng, c) for _ in range(c["steps"])]
+    noises = []
+    for _ in range(c["steps"]):
+        n = OrderedDict()
+        n["eps_actor"] = rng.standard_normal((B, A)).astype(f32)
+        n["eps_next"] = rng.standard_normal((B, A)).astype(f32)
+        n["u_rand"] = rng.uniform(-1.0, 1.0, size=(Bc * N, A)).astype(f32)
+        n["eps_pi"] = rng.standard_normal((Bc * N, A)).astype(f32)
+        n["eps_next_pi"] = rng.standard_normal((Bc * N, A)).astype(f32)
+        noises.append(n)
+    return c, state, batches, noises
+
+
+def combo_cfg(c):
+    """oracle/cql.py configuration of a COMBO case (run_combo.py:63-82 defaults)"""
+    B = c["B_real"] + c["B_fake"]
+    over = dict(c["over"])
+    rho = over.pop("rho_s", "mix")
+    cfg = dict(hidden=c["hidden"], num_repeat_actions=c["N"], with_lagrange=False, cql_alpha_lr=3e-4, cql_weight=5.0,
+               cons_rows=(c["B_real"], c["B_fake"]) if rho == "model" else (0, B), real_rows=c["B_real"])
+    cfg.update(over)
+    return cfg

@@ -83,3 +83,23 @@ def generic_oracle_setup(algo, case):
     st = clone_state(st)
     mod.init_opt(st)
     return mod, cfg, st, batches, noises
+
+
+def mopo_oracle_setup(case):
+    from oracle import sac as osac
+    c, st, batches, noises = synth.mopo_case_inputs(case)
+    cfg = osac.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    st = clone_state(st)
+    osac.init_opt(st)
+    return cfg, st, batches, noises
+
+
+def combo_oracle_setup(case):
+    from oracle import cql as ocql
+    c, st, batches, noises = synth.combo_case_inputs(case)
+    cfg = ocql.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(synth.combo_cfg(c))
+    st = clone_state(st)
+    ocql.init_opt(st)
+    return cfg, st, batches, noises

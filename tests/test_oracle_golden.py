@@ -103,3 +103,50 @@ def test_torch_cpu_counterpart_of_cql_matches_reference(case):
         assert list(res.keys()) == keys
         got = np.array([res[x] for x in keys])
         assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 2e-5, (case, k, got, g[f"step{k}/losses"])
+
+
+NETS5 = ("actor", "critic1", "critic2", "critic1_old", "critic2_old")
+
+
+@pytest.mark.parametrize("case", list(synth.MOPO_CASES))
+def test_sac_oracle_matches_reference_mopo_learn(case):
+    """MOPOPolicy.learn = SACPolicy.learn on torch.cat([real, fake]) (mopo.py:81-84, sac.py:88-140)"""
+    from helpers import mopo_oracle_setup
+    from oracle import sac as osac
+    g = load_golden(case)
+    cfg, st, batches, noises = mopo_oracle_setup(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, aux = osac.learn(st, cfg, synth.mix_batch(b), n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (case, k, got, g[f"step{k}/losses"])
+        if k == 0:
+            assert scale_err(aux["q1"], g["step0/c1_q"]) < 1e-5 and scale_err(aux["q1a"], g["step0/c1_qa"]) < 1e-5
+        if k in (0, len(batches) - 1):
+            check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in NETS5}, atol=2e-6 * (k + 1))
+            if cfg["auto_alpha"]:
+                assert abs(float(st["log_alpha"][0]) - float(g[f"state{k}/log_alpha"][0])) < 1e-6
+
+
+@pytest.mark.parametrize("case", list(synth.COMBO_CASES))
+def test_cql_oracle_matches_reference_combo_learn(case):
+    """COMBOPolicy.learn (combo.py:110-241): the CQL update on the mixed batch, conservative rows from rho_s, data term on real rows"""
+    from helpers import combo_oracle_setup
+    from oracle import cql as ocql
+    g = load_golden(case)
+    cfg, st, batches, noises = combo_oracle_setup(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    Br = cfg["real_rows"]
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, aux = ocql.learn(st, cfg, synth.mix_batch(b), n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (case, k, got, g[f"step{k}/losses"])
+        if k == 0:
+            assert scale_err(aux["q1"], g["step0/c1_q"]) < 1e-5 and scale_err(aux["q1a"], g["step0/c1_qa"]) < 1e-5
+            assert scale_err(aux["q1"][:Br], g["step0/c1_q_real"]) < 1e-5          # the separate forward on the real rows = the first Br rows
+            assert scale_err(aux["cat_q1"][:, 2] + np.log(0.5 ** cfg["act_dim"]), g["step0/c1_q_rand"][:, 0]) < 1e-5
+        if k in (0, len(batches) - 1):
+            check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in NETS5}, atol=2e-6 * (k + 1))
+            assert abs(float(st["cql_log_alpha"][0]) - float(g[f"state{k}/cql_log_alpha"][0])) < 1e-6
