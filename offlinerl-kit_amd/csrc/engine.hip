@@ -744,7 +744,8 @@ static int launch_sample(Engine* e, const Mat& head, int A, const SampleJob* job
   int maxrows = 0;
   for (int i = 0; i < njobs; ++i) { sp.job[i] = jobs[i]; maxrows = std::max(maxrows, jobs[i].rows); }
   e->prof_begin("tanh_sample", 0);
-  hipLaunchKernelGGL(k_tanh_sample, dim3((maxrows + 255) / 256, njobs, e->R), dim3(256), 0, e->stream, sp);
+  const int AG = A <= 8 ? 8 : (A <= 16 ? 16 : 32);      // lanes per output row (k_tanh_sample)
+  hipLaunchKernelGGL(k_tanh_sample, dim3((unsigned)(((long)maxrows * AG + 255) / 256), njobs, e->R), dim3(256), 0, e->stream, sp);
   e->prof_end();
   return hipGetLastError() == hipSuccess ? 0 : fail("tanh_sample launch");
 }
@@ -902,7 +903,11 @@ int Engine::enqueue_prepare(bool sampling, bool devnoise) {
     PrepJob j = s.job;
     const long n_el = (long)j.rows * j.width;
     if (n_el > (1L << 30)) return fail("prepare job too large");
-    j.units = (int)((j.src == PS_NORMAL || j.src == PS_UNIFORM) ? (n_el + 3) / 4 : n_el);
+    // 16-byte units for gathers of >= 4 columns between 16-byte aligned rows (dataset / batch-slot rows are zero-padded to OP / AP)
+    const bool gather = j.src == PS_OBS || j.src == PS_NOBS || j.src == PS_ACT;
+    j.vec4 = gather && j.width >= 4 && (j.dst_col0 & 3) == 0 && (j.dst_pitch & 3) == 0 && (j.dst_rs & 3) == 0 && aligned16(j.dst) &&
+             ((j.width + 3) & ~3) <= (j.src == PS_ACT ? AP : OP);
+    j.units = (int)((j.src == PS_NORMAL || j.src == PS_UNIFORM) ? (n_el + 3) / 4 : (j.vec4 ? (long)j.rows * ((j.width + 3) / 4) : n_el));
     blocks += (j.units + 255) / 256;
     j.block_end = blocks;
     p.job[p.njobs++] = j;

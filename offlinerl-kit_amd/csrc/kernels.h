@@ -154,6 +154,7 @@ struct PrepJob {
   int block_end;        // exclusive end of this job's range of 256-thread blocks (per run): a block serves ONE job, so the job lookup
                         // is a scalar loop; a thread's unit = one element, or four for the noise jobs
   int units;            // work units of the job
+  int vec4;             // gather jobs whose source rows and destination rows are 16-byte aligned: a unit = four consecutive columns
   float* dst; long dst_rs; int dst_pitch, dst_row0, dst_col0;
   int rows, width;      // output region: rows x width
   int src;              // PS_*
@@ -211,6 +212,32 @@ __global__ void k_prepare(PrepP p) {
     for (int k = 0; k < 4; ++k) {
       if (e0 + k < n_el) d[(long)row * jb.dst_pitch + col] = v[k];
       if (++col == jb.width) { col = 0; ++row; }
+    }
+    return;
+  }
+  if (jb.vec4) {
+    // four columns per thread: one 16-byte load from the (zero-padded, 16-byte aligned) source row, one 16-byte store -- or scalar
+    // stores for the chunk that holds the row's last columns (the columns behind them belong to another job)
+    const int chunks = (jb.width + 3) >> 2;
+    const int row = u / chunks, c4 = (u - row * chunks) << 2;
+    const int b = jb.src_row0 + (jb.mod ? row % jb.mod : row) / jb.rep;
+    const float* srow;
+    if (p.d_obs) {
+      const long j = p.idx[(long)r * p.idx_rs + b];
+      srow = (jb.src == PS_OBS ? p.d_obs : (jb.src == PS_NOBS ? p.d_nobs : p.d_act)) + j * (jb.src == PS_ACT ? p.AP : p.OP);
+    } else {
+      srow = jb.src == PS_ACT ? p.b_act + (long)r * p.ba_rs + (long)b * p.b_ap
+                              : (jb.src == PS_OBS ? p.b_obs : p.b_nobs) + (long)r * p.bo_rs + (long)b * p.b_op;
+    }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 v = *(const f4*)(srow + c4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (c4 + k >= jb.ncopy) v[k] = 0.f;
+    float* d = jb.dst + (long)r * jb.dst_rs + (long)(jb.dst_row0 + row) * jb.dst_pitch + jb.dst_col0 + c4;
+    if (c4 + 4 <= jb.width) *(f4*)d = v;
+    else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c4 + k < jb.width) d[k] = v[k];
     }
     return;
   }
@@ -284,27 +311,32 @@ struct SampleP {
   SampleJob job[3];
 };
 __global__ void k_tanh_sample(SampleP p) {
+  // one thread per (output row, action): the A actions of a row sit in AG = 8 / 16 / 32 consecutive lanes (lanes >= A idle) and the
+  // row's log-probability is a shuffle reduction over that lane group (one thread per row looped over A with four transcendental
+  // calls per action and used a sixth of the lanes' parallelism)
   const SampleJob& jb = p.job[blockIdx.y];
   const int r = blockIdx.z;
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= jb.rows) return;
   const int A = p.A;
-  const float* h = p.head + (long)r * p.head_rs + (long)(jb.head_row0 + j / jb.rep) * (2 * A);
-  const float* e = jb.eps ? jb.eps + (long)r * jb.eps_rs + (long)j * A : nullptr;
-  float* d = jb.dst + (long)r * jb.dst_rs + (long)(jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col;
-  float lp = 0.f, lj = 0.f;
-  for (int a = 0; a < A; ++a) {
+  const int AG = A <= 8 ? 8 : (A <= 16 ? 16 : 32);
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = t / AG, a = t - j * AG;
+  const bool on = j < jb.rows && a < A;
+  float term = 0.f;
+  if (on) {
+    const float* h = p.head + (long)r * p.head_rs + (long)(jb.head_row0 + j / jb.rep) * (2 * A);
     const float mu = h[a];
     const float ls = fminf(fmaxf(h[A + a], -5.0f), 2.0f);
     const float sg = expf(ls);
-    const float u = e ? mu + sg * e[a] : mu;
+    const float u = jb.eps ? mu + sg * jb.eps[(long)r * jb.eps_rs + (long)j * A + a] : mu;
     const float act = tanhf(u);
-    d[a] = act;
+    jb.dst[(long)r * jb.dst_rs + (long)(jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col + a] = act;
     const float dm = u - mu;
-    lp += -(dm * dm) / (2.0f * (sg * sg)) - ls - ORL_LOG_SQRT_2PI;
-    lj += logf((1.0f - act * act) + 1e-6f);
+    term = (-(dm * dm) / (2.0f * (sg * sg)) - ls - ORL_LOG_SQRT_2PI) - logf((1.0f - act * act) + 1e-6f);
   }
-  if (jb.logp) jb.logp[(long)r * jb.logp_rs + j] = lp - lj;
+  // fixed-order tree over the lane group (the reference sums the A terms of logp and of the Jacobian separately, dist_module.py:27-31;
+  // the difference is fp32 reassociation of <= 32 terms)
+  for (int o = AG >> 1; o > 0; o >>= 1) term += __shfl_down(term, o, AG);
+  if (on && a == 0 && jb.logp) jb.logp[(long)r * jb.logp_rs + j] = term;
 }
 
 // block-wide sum over 256 threads (4 waves of 64)
