@@ -37,6 +37,7 @@ extern "C" {
 #define ORL_ALGO_TD3BC 2 /* policy/model_free/td3bc.py:83-124 */
 #define ORL_ALGO_EDAC 3  /* policy/model_free/edac.py:88-166  */
 #define ORL_ALGO_SAC 4   /* policy/model_free/sac.py:88-140 (MOPOPolicy.learn on the real+model batch, model_based/mopo.py:81-84) */
+#define ORL_ALGO_MCQ 5   /* policy/model_free/mcq.py:48-126 (SAC critics / actor + the VAE behaviour policy of nets/vae.py) */
 
 #define ORL_MAX_HIDDEN 4
 #define ORL_MAX_METRICS 8
@@ -50,7 +51,9 @@ extern "C" {
 #define ORL_NET_CRITIC2_OLD 4
 #define ORL_NET_CRITIC_V 5    /* IQL only  */
 #define ORL_NET_ACTOR_OLD 6   /* TD3BC only */
-#define ORL_NUM_NETS 7
+#define ORL_NET_VAE_ENC 7     /* MCQ behaviour policy (nets/vae.py): e1, e2, [mean; log_std] */
+#define ORL_NET_VAE_DEC 8     /*                                      d1, d2, d3            */
+#define ORL_NUM_NETS 9
 
 /* per-run scalars (not nn.Parameters in the reference: run_cql.py:102, cql.py:57) */
 #define ORL_SCALAR_LOG_ALPHA 0
@@ -70,6 +73,7 @@ extern "C" {
 #define ORL_OPT_ALPHA 2
 #define ORL_OPT_CQL_ALPHA 3
 #define ORL_OPT_CRITIC_V 4
+#define ORL_OPT_VAE 5      /* MCQ behavior_policy_optim */
 
 typedef struct orl_config {
   int32_t algo;
@@ -106,6 +110,10 @@ typedef struct orl_config {
    * model rollouts.  The conservative term repeats rows [cql_cons_row0, cql_cons_row0 + cql_cons_rows) ("model": the model part,
    * "mix": the whole batch) and its -w mean Q term runs over the real rows only.  0 = the whole batch (plain CQL). */
   int32_t cql_cons_row0, cql_cons_rows, cql_real_rows;
+  /* MCQ (mcq.py:19-46, run_mcq.py:34-36, 93-101): VAE hidden width / latent size, lambda, behaviour-policy lr; the number of sampled
+   * actions is num_repeat_actions, the VAE's max_action is max_action */
+  int32_t vae_hidden, vae_latent;
+  float mcq_lambda, behavior_lr;
   /* optional caller-owned parameter arena (device pointer, orl_arena_floats()
    * floats) so that framework tensors can alias engine parameters; NULL = the
    * engine allocates with hipMalloc. */
@@ -127,6 +135,8 @@ typedef struct orl_batch {
  * CQL: [0] eps_actor (B,A) N(0,1); [1] eps_next (B,A) or (B*N,A) with
  * max_q_backup; [2] u_rand (B*N,A) U[low,high); [3] eps_pi (B*N,A); [4] eps_next_pi (B*N,A).
  * EDAC: [0] eps_actor, [1] eps_next.  TD3BC: [0] eps_target (B,A).  IQL: none.  SAC: [0] eps_next, [1] eps_actor (B,A).
+ * MCQ: [0] eps_vae (B,Z), [1] eps_next (B,A), [2] z_ood (2B*N,Z) N(0,1) (clamped to +-0.5 by the engine like VAE.decode), [3] eps_ood (2B,A),
+ * [4] eps_actor (B,A).
  * Each array has a leading n_runs dimension. */
 typedef struct orl_noise {
   const float* slot[ORL_MAX_NOISE];

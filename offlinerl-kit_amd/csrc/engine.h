@@ -132,7 +132,7 @@ struct Engine {
   std::set<const void*> bits_live;   // mask-bit buffers whose producer launch emitted them this step (decided on the host)
   struct Tap { Mat m; long rows; int cols; };
   std::map<std::string, Tap> taps;
-  struct NoiseSlot { std::string name; int kind; int rows; };
+  struct NoiseSlot { std::string name; int kind; int rows; int cols = 0; };      // cols 0 = act_dim
   std::vector<NoiseSlot> noise_slots;
   // k_prepare job list (algorithms that use it skip the separate gather / noise / assemble launches)
   struct PrepSpec { PrepJob job; int need_sampling; int need_devnoise; };   // -1 any, 0 no, 1 yes
@@ -189,6 +189,7 @@ struct Engine {
   int td3bc_build(); int td3bc_step(bool actor_step);
   int edac_build(); int edac_step();
   int sac_build(); int sac_step();
+  int mcq_build(); int mcq_step();
 };
 
 }  // namespace orl

@@ -84,6 +84,41 @@ static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind 
   return l;
 }
 
+// MCQ's behaviour policy (nets/vae.py:8-66) as two MLP families whose tensors carry the reference's parameter names:
+//   encoder e1, e2 (ReLU) + tail [mean ; log_std] stored as one (2Z x VH) matrix;  decoder d1, d2 (ReLU) + tail d3
+static NetLayout make_vae_layout(bool encoder, int in_dim, int vh, int out_dim) {
+  NetLayout l;
+  l.present = true;
+  l.in_dim = in_dim; l.L = 2; l.out_dim = encoder ? 2 * out_dim : out_dim;
+  const char* n0 = encoder ? "e1" : "d1";
+  const char* n1 = encoder ? "e2" : "d2";
+  long off = 0;
+  int d = in_dim;
+  const char* names[2] = {n0, n1};
+  for (int i = 0; i < 2; ++i) {
+    l.H[i] = vh;
+    l.w_off[i] = off; add_tensor(l, std::string(names[i]) + ".weight", off, {vh, d}); off += (long)vh * d;
+    l.b_off[i] = off; add_tensor(l, std::string(names[i]) + ".bias", off, {vh}); off += vh;
+    d = vh;
+  }
+  l.w_off[2] = off;
+  if (encoder) {
+    add_tensor(l, "mean.weight", off, {out_dim, d});
+    add_tensor(l, "log_std.weight", off + (long)out_dim * d, {out_dim, d});
+    off += 2L * out_dim * d;
+    l.b_off[2] = off;
+    add_tensor(l, "mean.bias", off, {out_dim});
+    add_tensor(l, "log_std.bias", off + out_dim, {out_dim});
+    off += 2 * out_dim;
+  } else {
+    add_tensor(l, "d3.weight", off, {out_dim, d}); off += (long)out_dim * d;
+    l.b_off[2] = off; add_tensor(l, "d3.bias", off, {out_dim}); off += out_dim;
+  }
+  l.size = off;
+  for (int i = 0; i <= 2; ++i) l.w_ms[i] = l.b_ms[i] = l.stride();
+  return l;
+}
+
 // EnsembleCritic (modules/ensemble_critic_module.py:11-31): model.{0,2,..}.weight (K,in,out), .bias (K,1,out)
 static NetLayout make_ensemble_layout(int in_dim, const int* hidden, int L, int K) {
   NetLayout l;
@@ -116,10 +151,15 @@ static int build_layouts(const orl_config& c, NetLayout* lay, long* net_off, boo
   long o = 0, t = 0;
   auto train = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = o; o += l.stride(); };
   auto target = [&](int id, const NetLayout& l) { lay[id] = l; net_off[id] = t; is_tgt[id] = true; t += l.stride(); };
-  if (c.algo == ORL_ALGO_CQL || c.algo == ORL_ALGO_SAC) {
+  if (c.algo == ORL_ALGO_CQL || c.algo == ORL_ALGO_SAC || c.algo == ORL_ALGO_MCQ) {
     train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_TANH_GAUSS, ad));
     train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
     target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
+    if (c.algo == ORL_ALGO_MCQ) {
+      if (c.vae_hidden < 1 || c.vae_latent < 1 || c.vae_latent > 64) return fail("MCQ: vae_hidden / vae_latent out of range");
+      train(ORL_NET_VAE_ENC, make_vae_layout(true, od + ad, c.vae_hidden, c.vae_latent));
+      train(ORL_NET_VAE_DEC, make_vae_layout(false, od + c.vae_latent, c.vae_hidden, ad));
+    }
   } else if (c.algo == ORL_ALGO_IQL) {
     train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_GAUSS, ad));
     train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
@@ -765,6 +805,7 @@ static SampleJob make_job(int head_row0, int rows, int rep, const Mat& eps, cons
 #include "algo_td3bc.inc"
 #include "algo_edac.inc"
 #include "algo_sac.inc"
+#include "algo_mcq.inc"
 
 namespace orl {
 
@@ -823,6 +864,7 @@ int Engine::init(const orl_config& c) {
   hyper_host.lr[ORL_OPT_ALPHA] = c.alpha_lr;
   hyper_host.lr[ORL_OPT_CQL_ALPHA] = c.cql_alpha_lr;
   hyper_host.lr[ORL_OPT_CRITIC_V] = c.critic_v_lr;
+  hyper_host.lr[ORL_OPT_VAE] = c.behavior_lr;
   ORL_HIP(hipMemcpyAsync(hyper, &hyper_host, sizeof(Hyper), hipMemcpyHostToDevice, stream));
   std::vector<RunScalars> sc(R);
   for (auto& s : sc) { memset(&s, 0, sizeof(s)); s.alpha = c.auto_alpha ? 1.0f : c.alpha; s.alpha_bwd = s.alpha; s.cons_scale = 1.f; }
@@ -839,9 +881,10 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_TD3BC: rc = td3bc_build(); break;
     case ORL_ALGO_EDAC: rc = edac_build(); break;
     case ORL_ALGO_SAC: rc = sac_build(); break;
+    case ORL_ALGO_MCQ: rc = mcq_build(); break;
   }
   if (rc) return rc;
-  for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ad};      // the noise arrays of the last step
+  for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ns.cols ? ns.cols : ad};      // the noise arrays of the last step
   nm = (int)metric_names.size();
   if (nm > ORL_MAX_METRICS) return fail("too many metrics");
   metrics_last = raw_alloc(sizeof(float) * R * nm);
@@ -946,6 +989,7 @@ int Engine::enqueue_step(int variant) {
     case ORL_ALGO_TD3BC: rc = td3bc_step(variant == 1); break;
     case ORL_ALGO_EDAC: rc = edac_step(); break;
     case ORL_ALGO_SAC: rc = sac_step(); break;
+    case ORL_ALGO_MCQ: rc = mcq_step(); break;
   }
   if (rc) return rc;
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, stream, gstep);
@@ -989,6 +1033,8 @@ void orl_config_default(orl_config* c, int32_t algo) {
   if (algo == ORL_ALGO_IQL || algo == ORL_ALGO_TD3BC) { c->actor_lr = 3e-4f; }
   if (algo == ORL_ALGO_EDAC) { c->n_hidden = 3; c->hidden[2] = 256; c->deterministic_backup = 0; }
   if (algo == ORL_ALGO_SAC) { c->actor_lr = 1e-4f; c->critic_lr = 3e-4f; c->deterministic_backup = 0; }   /* run_mopo.py:33-34 */
+  c->vae_hidden = 750; c->vae_latent = 2 * c->act_dim; c->mcq_lambda = 0.9f; c->behavior_lr = 1e-3f;   /* run_mcq.py:34-36, 93-99 */
+  if (algo == ORL_ALGO_MCQ) { c->hidden[0] = c->hidden[1] = 400; c->actor_lr = c->critic_lr = c->alpha_lr = 3e-4f; c->target_entropy = -(float)c->act_dim; }
 }
 
 int64_t orl_arena_floats(const orl_config* cfg) {
@@ -1253,7 +1299,7 @@ int orl_step(orl_engine* h, const orl_batch* b, const orl_noise* nz, float* metr
   if (nz) {
     const bool dv = nz->on_device != 0;
     for (size_t i = 0; i < e.noise_slots.size(); ++i)
-      if (copy_rows(e, e.W(e.noise_slots[i].name), nz->slot[i], e.noise_slots[i].rows, e.ad, dv)) return -1;
+      if (copy_rows(e, e.W(e.noise_slots[i].name), nz->slot[i], e.noise_slots[i].rows, e.noise_slots[i].cols ? e.noise_slots[i].cols : e.ad, dv)) return -1;
   }
   if (!e.prep.empty()) { if (e.enqueue_prepare(false, nz == nullptr)) return -1; }
   else if (!nz) { if (e.enqueue_noise()) return -1; }

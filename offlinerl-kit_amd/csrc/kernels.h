@@ -920,6 +920,132 @@ __global__ void k_td3_actor_bwd(Td3ActorBwdP p) {
 }
 
 // ================================================================================================
+// MCQ (mcq.py:48-126; oracle/mcq.py): VAE behaviour policy (nets/vae.py) + in-distribution / OOD critic targets
+// ================================================================================================
+// encoder head -> latent: ehead = [mean | log_std_raw] (B x 2Z); ls = clamp(raw, -4, 15); std = exp(ls); z = mean + std * eps
+// writes z into the decoder input rows xd[:, od:od+Z] and keeps std.  grid (ceil(B*Z/256), R)
+struct VaeLatentP {
+  const float* ehead; long eh_rs;      // [R][B][2Z]
+  const float* eps; long eps_rs;       // [R][B][Z]
+  float* xd; long xd_rs; int xd_pitch, od;
+  float* stdv; long std_rs;            // [R][B][Z]
+  int B, Z;
+};
+__global__ void k_vae_latent(VaeLatentP p) {
+  const int r = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.B * p.Z) return;
+  const int b = t / p.Z, j = t - b * p.Z;
+  const float* h = p.ehead + (long)r * p.eh_rs + (long)b * 2 * p.Z;
+  const float sd = expf(fminf(fmaxf(h[p.Z + j], -4.0f), 15.0f));
+  p.stdv[(long)r * p.std_rs + t] = sd;
+  p.xd[(long)r * p.xd_rs + (long)b * p.xd_pitch + p.od + j] = h[j] + sd * p.eps[(long)r * p.eps_rs + t];
+}
+// loss = mse(max_a tanh(m3), a) + KL (vae.py:40-53, mcq.py:53-56): metric + d m3.  grid (R), block 256
+struct VaeLossP {
+  const float* m3; long m3_rs;         // [R][B][A] decoder output before tanh
+  const float* act; long act_rs; int apitch;
+  const float* ehead; long eh_rs;      // mean | log_std_raw
+  const float* stdv; long std_rs;
+  float* dm3;                          // [R][B][A]
+  int B, A, Z; float max_action; MetricsP m; int slot;
+};
+__global__ void k_vae_loss(VaeLossP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float s_rec = 0.f, s_kl = 0.f;
+  for (int t = threadIdx.x; t < p.B * p.A; t += 256) {
+    const int b = t / p.A, a = t - b * p.A;
+    const float th = tanhf(p.m3[(long)r * p.m3_rs + t]);
+    const float d = p.max_action * th - p.act[(long)r * p.act_rs + (long)b * p.apitch + a];
+    s_rec += d * d;
+    p.dm3[(long)r * p.m3_rs + t] = 2.0f * d / (float)(p.B * p.A) * p.max_action * (1.0f - th * th);
+  }
+  for (int t = threadIdx.x; t < p.B * p.Z; t += 256) {
+    const int b = t / p.Z, j = t - b * p.Z;
+    const float mean = p.ehead[(long)r * p.eh_rs + (long)b * 2 * p.Z + j];
+    const float sd = p.stdv[(long)r * p.std_rs + t];
+    s_kl += 1.0f + logf(sd * sd) - mean * mean - sd * sd;
+  }
+  s_rec = block_sum256(s_rec, sh);
+  s_kl = block_sum256(s_kl, sh);
+  if (threadIdx.x == 0) metric_set(p.m, r, p.slot, s_rec / (float)(p.B * p.A) - 0.5f * (s_kl / (float)(p.B * p.Z)));
+}
+// gradient of the encoder head: d mean = dz + mean / (B Z) ; d ls_raw = (dz std eps + (std^2 - 1) / (B Z)) gated by the clamp
+struct VaeHeadBwdP {
+  const float* dz; long dz_rs;         // [R][B][Z] gradient w.r.t. the latent columns of the decoder input
+  const float* ehead; long eh_rs; const float* stdv; long std_rs; const float* eps; long eps_rs;
+  float* dehead;                       // [R][B][2Z]
+  int B, Z;
+};
+__global__ void k_vae_head_bwd(VaeHeadBwdP p) {
+  const int r = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.B * p.Z) return;
+  const int b = t / p.Z, j = t - b * p.Z;
+  const float* h = p.ehead + (long)r * p.eh_rs + (long)b * 2 * p.Z;
+  const float dz = p.dz[(long)r * p.dz_rs + t], sd = p.stdv[(long)r * p.std_rs + t], lsr = h[p.Z + j];
+  const float inv = 1.0f / (float)(p.B * p.Z);
+  float* dh = p.dehead + (long)r * p.eh_rs + (long)b * 2 * p.Z;
+  dh[j] = dz + h[j] * inv;
+  dh[p.Z + j] = (lsr >= -4.0f && lsr <= 15.0f) ? dz * sd * p.eps[(long)r * p.eps_rs + t] + (sd * sd - 1.0f) * inv : 0.f;
+}
+// latent columns of the OOD decoder input: xdo[:, od:od+Z] = clamp(z, -0.5, 0.5) (vae.py:57-58).  grid (ceil(rows*Z/256), R)
+__global__ void k_clamp_latent(const float* z, long z_rs, float* xd, long xd_rs, int xd_pitch, int od, int rows, int Z) {
+  const int r = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * Z) return;
+  const int b = t / Z, j = t - b * Z;
+  xd[(long)r * xd_rs + (long)b * xd_pitch + od + j] = fminf(fmaxf(z[(long)r * z_rs + t], -0.5f), 0.5f);
+}
+// critic losses over the 3B rows [in-distribution B ; OOD 2B] (mcq.py:62-94):
+//   y_in = r + gamma (1 - d) (min_c qt_c - alpha logp') ; y_ood[j] = min_c max_n qto_c[j N + n]
+//   L_c = lambda mse(q_c[:B] - y_in) + (1 - lambda) mse(q_c[B:] - y_ood) ; dq accordingly.  grid (R), block 256
+struct McqLossP {
+  const float* q; long q_rs, q_cs; float* dq;        // [R][2][3B]
+  const float* qt; long qt_rs, qt_cs;                // target critics on (s', a') [R][2][B]
+  const float* qto; long qto_rs, qto_cs;             // target critics on the 2B*N sampled pairs [R][2][2BN]
+  const float* rew; const float* term; long bt_rs; const float* logp_next; long lpn_rs;
+  float* target_q; long tq_rs; float* target_ood; long to_rs;     // [R][B], [R][2B]
+  int B, N; float gamma, lambda;
+  const RunScalars* sc; int auto_alpha; float fixed_alpha; MetricsP m; int slot0;
+};
+__global__ void k_mcq_loss(McqLossP p) {
+  __shared__ float sh[4];
+  const int r = blockIdx.x, B = p.B;
+  const float alpha = p.auto_alpha ? p.sc[r].alpha : p.fixed_alpha;
+  float* yi = p.target_q + (long)r * p.tq_rs;
+  float* yo = p.target_ood + (long)r * p.to_rs;
+  const float* t0 = p.qt + (long)r * p.qt_rs;
+  const float* o0 = p.qto + (long)r * p.qto_rs;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float nq = fminf(t0[b], t0[p.qt_cs + b]) - alpha * p.logp_next[(long)r * p.lpn_rs + b];
+    yi[b] = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
+  }
+  for (int j = threadIdx.x; j < 2 * B; j += 256) {
+    float m0 = -INFINITY, m1 = -INFINITY;
+    for (int n = 0; n < p.N; ++n) { m0 = fmaxf(m0, o0[(long)j * p.N + n]); m1 = fmaxf(m1, o0[p.qto_cs + (long)j * p.N + n]); }
+    yo[j] = fminf(m0, m1);
+  }
+  __syncthreads();
+  for (int c = 0; c < 2; ++c) {
+    const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
+    float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
+    float s_in = 0.f, s_ood = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const float d = q[b] - yi[b];
+      s_in += d * d;
+      dq[b] = p.lambda * 2.0f * d / (float)B;
+    }
+    for (int j = threadIdx.x; j < 2 * B; j += 256) {
+      const float d = q[B + j] - yo[j];
+      s_ood += d * d;
+      dq[B + j] = (1.0f - p.lambda) * 2.0f * d / (float)(2 * B);
+    }
+    s_in = block_sum256(s_in, sh);
+    s_ood = block_sum256(s_ood, sh);
+    if (threadIdx.x == 0) metric_set(p.m, r, p.slot0 + c, p.lambda * (s_in / (float)B) + (1.0f - p.lambda) * (s_ood / (float)(2 * B)));
+  }
+}
+
+// ================================================================================================
 // EDAC gradient-diversity term (edac.py:136-149; oracle/edac.py): from g[k][b][:] = dQ_k/da
 //   L_g = mean_b sum_{i!=j} <g^_i, g^_j> / (K-1) ; gamma = d(eta L_g)/dg.   One thread per batch row.
 // grid (ceil(B/64), R), block 64; K*A <= 640 values per row kept in registers/LDS-free loops.

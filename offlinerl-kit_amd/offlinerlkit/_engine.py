@@ -15,16 +15,16 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "liborlengine.so")
 
-ALGO_CQL, ALGO_IQL, ALGO_TD3BC, ALGO_EDAC, ALGO_SAC = 0, 1, 2, 3, 4
-ALGO_ID = {"cql": ALGO_CQL, "iql": ALGO_IQL, "td3bc": ALGO_TD3BC, "edac": ALGO_EDAC, "sac": ALGO_SAC}
+ALGO_CQL, ALGO_IQL, ALGO_TD3BC, ALGO_EDAC, ALGO_SAC, ALGO_MCQ = 0, 1, 2, 3, 4, 5
+ALGO_ID = {"cql": ALGO_CQL, "iql": ALGO_IQL, "td3bc": ALGO_TD3BC, "edac": ALGO_EDAC, "sac": ALGO_SAC, "mcq": ALGO_MCQ}
 MAX_HIDDEN, MAX_METRICS, MAX_NOISE = 4, 8, 6
-NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC1_OLD, NET_CRITIC2_OLD, NET_CRITIC_V, NET_ACTOR_OLD = range(7)
-NUM_NETS = 7
+NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC1_OLD, NET_CRITIC2_OLD, NET_CRITIC_V, NET_ACTOR_OLD, NET_VAE_ENC, NET_VAE_DEC = range(9)
+NUM_NETS = 9
 SCALAR_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA, SCALAR_ALPHA = 0, 1, 2
 SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA_M, SCALAR_CQL_LOG_ALPHA_V, SCALAR_LAST_ACTOR_LOSS = 3, 4, 5, 6, 7
 ALL_SCALARS = (SCALAR_LOG_ALPHA, SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA_M,
                SCALAR_CQL_LOG_ALPHA_V, SCALAR_LAST_ACTOR_LOSS, SCALAR_ALPHA)      # set order: ALPHA last (LOG_ALPHA derives it)
-OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V = range(5)
+OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V, OPT_VAE = range(6)
 
 # symbols include/orl_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -55,6 +55,7 @@ class OrlConfig(C.Structure):
         ("update_actor_freq", C.c_int32),
         ("num_critics", C.c_int32), ("eta", C.c_float),
         ("cql_cons_row0", C.c_int32), ("cql_cons_rows", C.c_int32), ("cql_real_rows", C.c_int32),
+        ("vae_hidden", C.c_int32), ("vae_latent", C.c_int32), ("mcq_lambda", C.c_float), ("behavior_lr", C.c_float),
         ("external_arena", C.c_void_p),
     ]
 
@@ -268,7 +269,7 @@ class Engine:
         _check(self.lib.orl_set_step_count(self._h, int(steps)), "orl_set_step_count")
 
     def trainable_nets(self) -> List[int]:
-        return [n for n in range(NUM_NETS) if self.net_present(n) and n in (NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC_V)]
+        return [n for n in range(NUM_NETS) if self.net_present(n) and n in (NET_ACTOR, NET_CRITIC1, NET_CRITIC2, NET_CRITIC_V, NET_VAE_ENC, NET_VAE_DEC)]
 
     def optimizer_state(self, run: int = 0) -> Dict:
         """Everything torch.optim state_dict()s would hold for this run: per-net Adam moments, the scalar optimizers, the step count."""

@@ -74,3 +74,38 @@ class EnsembleLinear(nn.Module):
 
     def get_decay_loss(self) -> torch.Tensor:
         return self.weight_decay * 0.5 * (self.weight ** 2).sum()
+
+
+class VAE(nn.Module):
+    """Vanilla conditional VAE, MCQ's behaviour policy (reference: offlinerlkit/nets/vae.py:8-66): encoder e1, e2 -> mean, log_std
+    (clamped to [-4, 15]); decoder d1, d2, d3 -> max_action * tanh; ``decode`` without a latent samples N(0, 1) clipped to +-0.5.
+    As with the other nets this describes the parameters and serves evaluation; MCQPolicy.learn runs in the HIP engine."""
+
+    def __init__(self, input_dim: int, output_dim: int, hidden_dim: int, latent_dim: int, max_action, device: str = "cpu") -> None:
+        super().__init__()
+        self.e1 = nn.Linear(input_dim + output_dim, hidden_dim)
+        self.e2 = nn.Linear(hidden_dim, hidden_dim)
+        self.mean = nn.Linear(hidden_dim, latent_dim)
+        self.log_std = nn.Linear(hidden_dim, latent_dim)
+        self.d1 = nn.Linear(input_dim + latent_dim, hidden_dim)
+        self.d2 = nn.Linear(hidden_dim, hidden_dim)
+        self.d3 = nn.Linear(hidden_dim, output_dim)
+        self.max_action = max_action
+        self.latent_dim = latent_dim
+        self.device = torch.device(device)
+        self.to(device=self.device)
+
+    def forward(self, obs: torch.Tensor, action: torch.Tensor):
+        z = torch.relu(self.e1(torch.cat([obs, action], 1)))
+        z = torch.relu(self.e2(z))
+        mean = self.mean(z)
+        std = torch.exp(self.log_std(z).clamp(-4, 15))
+        z = mean + std * torch.randn_like(std)
+        return self.decode(obs, z), mean, std
+
+    def decode(self, obs: torch.Tensor, z=None) -> torch.Tensor:
+        if z is None:
+            z = torch.randn((obs.shape[0], self.latent_dim)).to(self.device).clamp(-0.5, 0.5)
+        a = torch.relu(self.d1(torch.cat([obs, z], 1)))
+        a = torch.relu(self.d2(a))
+        return self.max_action * torch.tanh(self.d3(a))

@@ -170,7 +170,8 @@ class EnginePolicy(BasePolicy):
         try:
             torch.manual_seed((int(base) + run) & 0x7FFFFFFFFFFFFFFF)
             out = {}
-            trainable = [nid for nid in nets if nid in (_engine.NET_ACTOR, _engine.NET_CRITIC1, _engine.NET_CRITIC2, _engine.NET_CRITIC_V)]
+            trainable = [nid for nid in nets if nid in (_engine.NET_ACTOR, _engine.NET_CRITIC1, _engine.NET_CRITIC2, _engine.NET_CRITIC_V,
+                                                        _engine.NET_VAE_ENC, _engine.NET_VAE_DEC)]
             for nid in trainable:
                 m = deepcopy(nets[nid]).cpu()
                 for sub in m.modules():

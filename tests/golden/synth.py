@@ -364,3 +364,50 @@ def combo_cfg(c):
                cons_rows=(c["B_real"], c["B_fake"]) if rho == "model" else (0, B), real_rows=c["B_real"])
     cfg.update(over)
     return cfg
+
+
+# ----------------------------------------------------------------------------
+# MCQ (policy/model_free/mcq.py): SAC critics / actor + a VAE behaviour policy (nets/vae.py)
+# ----------------------------------------------------------------------------
+MCQ_CASES = {
+    "mcq_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], vae_hidden=24, latent_dim=6, B=8, N=3, steps=5, seed=701, over={}),
+    "mcq_tiny_fixed_alpha": dict(obs_dim=4, act_dim=2, hidden=[32, 32], vae_hidden=16, latent_dim=4, B=8, N=2, steps=3, seed=702,
+                                 over=dict(auto_alpha=False, alpha=0.2, lmbda=0.7)),
+    # run_mcq.py defaults at the hopper shape: hidden [400,400], VAE hidden 750, latent 2 * act_dim, batch 256, 10 sampled actions
+    "mcq_hopper": dict(obs_dim=11, act_dim=3, hidden=[400, 400], vae_hidden=750, latent_dim=6, B=256, N=10, steps=3, seed=71, over={}),
+}
+
+
+def make_vae(rng, obs_dim, act_dim, hidden, latent):
+    net = OrderedDict()
+    for name, i, o in (("e1", obs_dim + act_dim, hidden), ("e2", hidden, hidden), ("mean", hidden, latent), ("log_std", hidden, latent),
+                       ("d1", obs_dim + latent, hidden), ("d2", hidden, hidden), ("d3", hidden, act_dim)):
+        b = 1.0 / np.sqrt(i)
+        net[f"{name}.weight"] = _uniform(rng, (o, i), b)
+        net[f"{name}.bias"] = _uniform(rng, (o,), b)
+    return net
+
+
+def mcq_case_inputs(case):
+    c = MCQ_CASES[case]
+    rng = np.random.RandomState(c["seed"])
+    state = _sac_like_state(rng, c)
+    state["behavior_policy"] = make_vae(rng, c["obs_dim"], c["act_dim"], c["vae_hidden"], c["latent_dim"])
+    B, A, Z, N = c["B"], c["act_dim"], c["latent_dim"], c["N"]
+    batches = [make_batch(rng, B, c["obs_dim"], A) for _ in range(c["steps"])]
+    noises = []
+    for _ in range(c["steps"]):
+        n = OrderedDict()
+        n["eps_vae"] = rng.standard_normal((B, Z)).astype(f32)
+        n["eps_next"] = rng.standard_normal((B, A)).astype(f32)
+        n["z_ood"] = rng.standard_normal((2 * B * N, Z)).astype(f32)
+        n["eps_ood"] = rng.standard_normal((2 * B, A)).astype(f32)
+        n["eps_actor"] = rng.standard_normal((B, A)).astype(f32)
+        noises.append(n)
+    return c, state, batches, noises
+
+
+def mcq_cfg(c):
+    cfg = dict(hidden=c["hidden"], vae_hidden=c["vae_hidden"], latent_dim=c["latent_dim"], num_sampled_actions=c["N"])
+    cfg.update(c["over"])
+    return cfg

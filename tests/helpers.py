@@ -103,3 +103,13 @@ def combo_oracle_setup(case):
     st = clone_state(st)
     ocql.init_opt(st)
     return cfg, st, batches, noises
+
+
+def mcq_oracle_setup(case):
+    from oracle import mcq as omcq
+    c, st, batches, noises = synth.mcq_case_inputs(case)
+    cfg = omcq.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(synth.mcq_cfg(c))
+    st = clone_state(st)
+    omcq.init_opt(st)
+    return cfg, st, batches, noises

@@ -150,3 +150,23 @@ def test_cql_oracle_matches_reference_combo_learn(case):
         if k in (0, len(batches) - 1):
             check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in NETS5}, atol=2e-6 * (k + 1))
             assert abs(float(st["cql_log_alpha"][0]) - float(g[f"state{k}/cql_log_alpha"][0])) < 1e-6
+
+
+@pytest.mark.parametrize("case", list(synth.MCQ_CASES))
+def test_mcq_oracle_matches_reference(case):
+    """MCQPolicy.learn (mcq.py:48-126): VAE behaviour-policy step, in-distribution + OOD critic targets, SAC actor / temperature"""
+    from helpers import mcq_oracle_setup
+    from oracle import mcq as omcq
+    g = load_golden(case)
+    cfg, st, batches, noises = mcq_oracle_setup(case)
+    keys = [str(k) for k in g["loss_keys"]]
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, aux = omcq.learn(st, cfg, b, n)
+        assert list(res.keys()) == keys
+        got = np.array([res[x] for x in keys])
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (case, k, got, g[f"step{k}/losses"])
+        if k == 0:
+            assert scale_err(aux["q1"], g["step0/c1_q"]) < 1e-5 and scale_err(aux["q1_ood"], g["step0/c1_q_ood"]) < 1e-5
+            assert scale_err(aux["q1a"], g["step0/c1_qa"]) < 1e-5
+        if k in (0, len(batches) - 1):
+            check_state_against_golden(g, f"state{k}", {nm: st[nm] for nm in NETS5 + ("behavior_policy",)}, atol=4e-6 * (k + 1))
