@@ -333,7 +333,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
-  if (epi == E_BIAS_RELU && this->cfg.precision == 1 && use_ws && !force_scalar && in_row0 == 0 && in_rows == in &&
+  if (epi == E_BIAS_RELU && ws_precision_ok() && !force_scalar && in_row0 == 0 && in_rows == in &&
       Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
@@ -343,7 +343,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     w.bias = nr.base + l.b_off[layer]; w.b_s0 = nr.rs; w.b_s1 = l.b_ms[layer];
     w.Y = Y.p; w.y_s0 = Y.rs; w.y_s1 = Y.cs; w.y_pitch = Y.pitch;
     w.mb = Y.bits; w.mb_s0 = Y.brs; w.mb_s1 = Y.bcs; w.mb_g = Y.bg;
-    w.M = M; w.nz1 = nr.nz1;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     const bool want_tail = tail_out && tail_fused && layer == l.L - 1 && l.out_dim == 1;
     if (want_tail) {
       w.tw = nr.base + l.w_off[l.L]; w.tw_s0 = nr.rs; w.tw_s1 = l.w_ms[l.L];
@@ -352,7 +352,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     }
     // With the single-output tail folded in, the backward pass of a many-row batch needs only the mask bits of this activation
     // (ws_dgrad_w0 / ws_wgrad's derived tail gradients): the activation itself then never goes to HBM.
-    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows;
+    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows && this->cfg.precision == 1;   // (the consumer of an elided activation, ws_wgrad's derived tail gradients, is split-bf16 only)
     if (elide) w.Y = nullptr;
     const bool ws_ok = ws_fwd_supported(w, in, out);
     bool fused0 = false;
@@ -514,7 +514,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   }
   // plain (materialised) dz through a 256 x 256 layer with the ReLU mask of the receiving activation: the weight-stationary kernel
   // in gradient mode (B = the weights viewed transposed, epilogue = mask from bits)
-  if (!dy.rank1 && !p.w0_out && maskH && p.aux_bits && col0 == 0 && ncols == in && this->cfg.precision == 1 && use_ws && !force_scalar &&
+  if (!dy.rank1 && !p.w0_out && maskH && p.aux_bits && col0 == 0 && ncols == in && ws_precision_ok() && !force_scalar &&
       dy.m.pitch == out && dX.pitch == in && (long)M * nz >= 4096) {
     WsFwdP w;
     memset(&w, 0, sizeof(w));
@@ -524,7 +524,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.Y = dX.p; w.y_s0 = dX.rs; w.y_s1 = dX.cs; w.y_pitch = dX.pitch;
     w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
-    w.M = M; w.nz1 = nr.nz1;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     if (ws_fwd_supported(w, out, in)) {
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
       hipError_t err = launch_ws_fwd(w, nz, stream);
@@ -873,6 +873,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
+  { const char* f = getenv("ORL_WS32"); use_ws32 = !(f && atoi(f) == 0); }
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {

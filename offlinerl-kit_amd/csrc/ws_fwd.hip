@@ -3,10 +3,15 @@
 
 namespace orl {
 
-template <bool TQ, bool L0, bool DG = false, bool SY = true>      // SY = false: the activation itself is not stored (TQ only)
+// F32 = true: exact fp32 arithmetic (v_mfma_f32_16x16x4_f32) with the same structure: the wave's weight slice is 128 VGPRs either
+// way (fp32 [256 x 32] vs bf16 hi + lo), the LDS image holds the fp32 rows themselves ([buf][row][256] floats, 16-byte chunks
+// XOR-swizzled with the row like the bf16 planes), and a lane's ds_read_b128 of four consecutive k feeds four MFMAs (the k order
+// inside a 16-wide step is free as long as the resident weight fragments use the same one).
+template <bool TQ, bool L0, bool DG = false, bool SY = true, bool F32 = false>      // SY = false: the activation itself is not stored (TQ only)
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
+  float* Af = ws_smem;                                             // F32: [buf][row][WS_K]
   float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
   unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
   float* Xl = (float*)(nbs + 2 * WS_ROWS * WS_NBP);                          // L0: [buf][row][32] narrow input rows (fp32, ones column at in0)
@@ -23,7 +28,22 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
 
   // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
-  bf16x8 bh[WS_CB][8], bl[WS_CB][8];
+  // F32: lane (li, lq) supplies W[n][k = 16 t + 4 lq .. + 3], t = 0..15 (element e of the float4 = MFMA k step e of block t)
+  bf16x8 bh[WS_CB][F32 ? 1 : 8], bl[WS_CB][F32 ? 1 : 8];
+  f32x4 bw[WS_CB][F32 ? 16 : 1];
+  if constexpr (F32) {
+#pragma unroll
+    for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(16 * t + 4 * lq) * p.w_sk;
+        if (p.w_sk == 1) bw[cb][t] = *(const f32x4*)src;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bw[cb][t][j] = src[(long)j * p.w_sk];
+        }
+      }
+  } else {
 #pragma unroll
   for (int cb = 0; cb < WS_CB; ++cb)
 #pragma unroll
@@ -37,8 +57,10 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
         ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
       }
     }
+  }
   // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
   bf16x8 b0h[WS_CB], b0l[WS_CB];
+  f32x4 b0w[WS_CB][2];                              // F32: k = 16 t + 4 lq + e
   if (L0) {
     const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
     const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
@@ -52,7 +74,16 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
         a[j] = k0 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k0 * p.w0_sk] : (k0 == p.in0 ? b0g[n] : 0.f);
         b[j] = k1 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k1 * p.w0_sk] : (k1 == p.in0 ? b0g[n] : 0.f);
       }
-      ws_split8(a, b, b0h[cb], b0l[cb]);
+      if constexpr (!F32) ws_split8(a, b, b0h[cb], b0l[cb]);
+      if constexpr (F32) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = 16 * t + 4 * lq + j;
+            b0w[cb][t][j] = k < p.in0 ? W0g[(long)n * p.w0_sn + (long)k * p.w0_sk] : (k == p.in0 ? b0g[n] : 0.f);
+          }
+      }
     }
   }
   // epilogue constants of this lane's columns n = ncol0 + 16 cb + 4 lq + r sit in LDS (not in 16 VGPRs next to the 128 VGPRs of
@@ -84,6 +115,10 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+      if constexpr (F32) {        // float4 #kq of row r at chunk kq ^ (r & 15)
+        *(f32x4*)(Af + (long)buf * WS_ROWS * WS_K + r * WS_K + ((kq ^ (r & 15)) << 2)) = st[i];
+        continue;
+      }
       bf16x4 h, l;
       orl_split4(st[i], h, l);
       // 16-byte chunk c = k / 8 of row r lives at chunk c ^ (r & 15): ds_read_b128 of a fragment column is then conflict-free
@@ -113,9 +148,15 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     for (int i = 0; i < 2; ++i) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];   // surplus threads: pad column 32
   };
   // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
+  f32x4 fx32[2];                                     // F32: the narrow-input fragments of prod_x (k = 16 t + 4 lq + e)
   auto prod_x = [&](int xbuf, int s, bf16x8& xah, bf16x8& xal) __attribute__((always_inline)) {
-    const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 8 * lq;
-    ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+    if constexpr (F32) {
+      const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 4 * lq;
+      fx32[0] = *(const f32x4*)xrow; fx32[1] = *(const f32x4*)(xrow + 16);
+    } else {
+      const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 8 * lq;
+      ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+    }
   };
   auto prod_block = [&](int g, int buf, int par, int s, int cb, const bf16x8& xah, const bf16x8& xal) __attribute__((always_inline)) {
     __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
@@ -123,18 +164,29 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     const int r = 16 * s + li;
     const long m = (long)g * WS_ROWS + r;
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
-    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+    if constexpr (F32) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_mfma_f32_16x16x4f32(b0w[cb][t][e], fx32[t][e], v, 0, 0, 0);
+    } else {
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
+      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
     const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
     *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
+    if constexpr (F32) {
+      *(f32x4*)(Af + (long)buf * WS_ROWS * WS_K + r * WS_K + (((k >> 2) ^ (r & 15)) << 2)) = v;
+    } else {
     bf16x4 h, l;
     orl_split4(v, h, l);
     const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
     *(bf16x4*)(dh + o) = h;
     *(bf16x4*)(dl + o) = l;
+    }
     nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
         (unsigned char)orl_mask4(v);
   };
@@ -295,6 +347,24 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       // the three products of a block are issued plane by plane (lo*hi, hi*lo, hi*hi over all four blocks) so that dependent MFMAs
       // on one accumulator are four instructions apart; operands swapped: D[n][m], lane holds C[m = li][n = 4 lq + r]
       // (fetching the fragments one k step ahead, behind the MFMAs that free their registers, measured no different: r02 A/B)
+      if constexpr (F32) {
+        // 32 k per step = two float4 chunks per lane and row block, 8 MFMA k steps x 4 accumulator blocks
+        const float* af = Af + (long)buf * WS_ROWS * WS_K;
+        f32x4 fa[WS_SUB][2];
+#pragma unroll
+        for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) fa[s][tt] = *(const f32x4*)&af[(16 * s + li) * WS_K + (((8 * ks + 4 * tt + lq) ^ li) << 2)];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+              for (int cb = 0; cb < WS_CB; ++cb)
+                acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[cb][2 * ks + tt][e], fa[s][tt][e], acc[s][cb], 0, 0, 0);
+      } else {
       bf16x8 fah2[WS_SUB], fal2[WS_SUB];
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
@@ -313,6 +383,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
         for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+      }
       if (fine) {
         if (!lead) piece(ks);
         __builtin_amdgcn_sched_barrier(0);
@@ -363,35 +434,47 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   finish(g - gs, (it - 1) & 1);
 }
 
+template <bool F32>
+static hipError_t ws_fwd_attrs() {
+  const int big = (int)ws_fwd_lds_bytes(true);
+  hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, false, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true, false, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, false, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  return e;
+}
+
+template <bool F32>
+static void ws_fwd_dispatch(const WsFwdP& p, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  const bool l0 = p.X0 != nullptr;
+  if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true, true, F32>), grid, block, lds, st, p);
+  else if (l0) {
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false, F32>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, true, F32>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, true, false, true, F32>), grid, block, lds, st, p);
+  } else {
+    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, false, false, false, F32>), grid, block, lds, st, p);
+    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false, false, true, F32>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, false, false, true, F32>), grid, block, lds, st, p);
+  }
+}
+
 hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
   // one workgroup per CU (register-resident weights): whole rounds of 256 workgroups over the nz problems (ws_blocks_per_problem)
   const int per_z = ws_blocks_per_problem(p.groups, nz, 10, 1 << 20);
-  const bool l0 = p.X0 != nullptr;
-  const size_t lds = ws_fwd_lds_bytes(l0);
+  const size_t lds = ws_fwd_lds_bytes(p.X0 != nullptr);
   static const hipError_t attr_err = [] {       // thread-safe one-time initialisation (engines may launch from several host threads)
-    const int big = (int)ws_fwd_lds_bytes(true);
-    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-    return e;
+    hipError_t e = ws_fwd_attrs<false>();
+    return e == hipSuccess ? ws_fwd_attrs<true>() : e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 1, nz), block(WS_NT);
-  if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true>), grid, block, lds, st, p);
-  else if (l0) {
-    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false>), grid, block, lds, st, p);
-    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((ws_fwd_kernel<false, true>), grid, block, lds, st, p);
-  } else {
-    if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, false, false, false>), grid, block, lds, st, p);
-    else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, false>), grid, block, lds, st, p);
-    else hipLaunchKernelGGL((ws_fwd_kernel<false, false>), grid, block, lds, st, p);
-  }
+  if (p.f32) ws_fwd_dispatch<true>(p, grid, block, lds, st);
+  else ws_fwd_dispatch<false>(p, grid, block, lds, st);
   return hipGetLastError();
 }
 

@@ -47,6 +47,7 @@ struct WsFwdP {
   // plain dgrad mode (template DG): Y = (X B^T) (.) mask, B given by the strides above (W viewed transposed), no bias / ReLU / mask
   // emission; `dmask` = packed ReLU mask of the activation the gradient flows into
   const unsigned int* dmask; long dm_s0, dm_s1; int dm_g;
+  int f32;                                              // exact fp32 arithmetic (v_mfma_f32_16x16x4_f32) instead of split bf16
 };
 
 #ifndef WS_WAVES

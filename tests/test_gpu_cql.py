@@ -209,6 +209,35 @@ def test_cql_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
         eng4.close(); eng1.close()
 
 
+def test_cql_fp32_weight_stationary_forward_matches_tiled_kernels(monkeypatch):
+    """Exact fp32, full size: the weight-stationary forward's fp32 variant (ws_fwd_kernel<..., F32 = true>: v_mfma_f32_16x16x4_f32,
+    fused first layer, fused tail, mask bits, plain-dgrad mode) against an engine created with ORL_WS32=0, which keeps precision 0
+    on the tiled fp32 kernels.  Same inputs, both exact fp32 products with fp32 accumulation in a different summation order ->
+    losses agree to a few ulps of the reductions, updated parameters to Adam's sensitivity at near-zero gradients."""
+    case = "cql_halfcheetah"
+    R = 4
+    eng4, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=0)
+    monkeypatch.setenv("ORL_WS32", "0")           # read at engine creation
+    eng1, _, _, _, _ = make_engine(case, n_runs=1, precision=0)
+    monkeypatch.delenv("ORL_WS32")
+    try:
+        worst = 0.0
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            m4 = eng4.step(lead(b, R), lead(noise_list(n), R))
+            m1 = eng1.step(lead(b), lead(noise_list(n)))[0]
+            for r in range(R):
+                worst = max(worst, rel_err(m4[r], m1, floor=1e-2))
+        assert worst < 2e-6, worst
+        for nm in ("critic1", "critic2", "actor"):
+            a, b1 = eng4.get_net(R - 1, NETS[nm]), eng1.get_net(0, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < 2e-7, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < 2e-4, (nm, pn)
+    finally:
+        eng4.close(); eng1.close()
+
+
 @pytest.mark.parametrize("case", list(synth.CQL_EXTRA_CASES) + ["cql_halfcheetah_h3"])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_cql_many_runs_kernel_selection_corners(case, precision):
