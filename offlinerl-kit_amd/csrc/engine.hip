@@ -352,7 +352,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     }
     // With the single-output tail folded in, the backward pass of a many-row batch needs only the mask bits of this activation
     // (ws_dgrad_w0 / ws_wgrad's derived tail gradients): the activation itself then never goes to HBM.
-    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows && this->cfg.precision == 1;   // (the consumer of an elided activation, ws_wgrad's derived tail gradients, is split-bf16 only)
+    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows;
     if (elide) w.Y = nullptr;
     const bool ws_ok = ws_fwd_supported(w, in, out);
     bool fused0 = false;
@@ -453,7 +453,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   }
   // weight-stationary fused kernel (csrc/ws_gemm.h): top-layer dgrad from mask bits + layer-0 weight gradient, nothing stored
   if (w0_X && w0_slabs && !store_dx && maskH && dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar &&
-      this->cfg.precision == 1 && use_ws && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
+      ws_precision_ok() && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
       ncols == in && (long)M * nz >= 4096) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
@@ -466,7 +466,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
     w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
-    w.M = M; w.nz1 = nr.nz1;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab);
       prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
@@ -479,7 +479,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     }
   }
   // same kernel, storing variant (no layer-0 gradient): e.g. the critic backward of the actor loss, where dz0 feeds dL/da
-  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !force_scalar && this->cfg.precision == 1 && use_ws && p.aux_bits &&
+  if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !force_scalar && ws_precision_ok() && p.aux_bits &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= 4096) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
@@ -490,7 +490,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
-    w.M = M; w.nz1 = nr.nz1;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, 1 << 20);
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
@@ -618,7 +618,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   if (slabs_out) *slabs_out = ksplit;
   // output-stationary kernel (csrc/ws_gemm.h): dz^T from the packed ReLU mask, G = dq (.) X and the activation itself streamed once;
   // the tail layer's gradients ride along (*fuse_tail = true, same slabs)
-  if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && this->cfg.precision == 1 && use_ws && !force_scalar && !l.ens &&
+  if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && ws_precision_ok() && !force_scalar && !l.ens &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && in_row0 == 0 && in_rows == in && X.pitch == in &&
       (long)M * nz >= ws_wgrad_min_rows) {
     const bool derived = vals_dead.count(dy.m.p) > 0;
@@ -637,7 +637,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       w.b1 = nr.base + l.b_off[layer]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[layer];
     } else { w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch; }
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
-    w.M = M; w.nz1 = nr.nz1;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
       prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,

@@ -200,10 +200,193 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       }
 }
 
+// ---- exact-fp32 flavour (precision 0): same structure on v_mfma_f32_16x16x4_f32 ----
+// Resident B'[k][n] = w_tail[k] W1[k][n] as fp32 (lane (li, lq): n = ncol0 + 16 cb + li, k = 16 t + 4 lq + e: 128 VGPRs), the 0/1
+// mask of h1 expanded from its bits into an fp32 LDS image (16-byte chunks XOR-swizzled with the row, as in ws_fwd's fp32 image;
+// a lane's ds_read_b128 = four MFMA k steps), and dW0^T += X^T dz0 on the same instruction with the accumulators as B operand
+// (k step r = the lane's row 4 lq + r) and X^T rows read as float4 from an fp32 image.
+enum { WD32_XP = WS_ROWS + 4 };                                      // float pitch of an X^T row
+static constexpr size_t ws_dgrad32_lds_bytes() {
+  return sizeof(float) * ((size_t)2 * WS_ROWS * WS_K + (size_t)2 * 32 * WD32_XP + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS));
+}
+
+template <bool W0, bool STORE>
+__global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) {
+  static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  float* Am = ws_smem;                                              // [buf][row][256] 0/1 mask as fp32, swizzled
+  float* XT = Am + 2 * WS_ROWS * WS_K;                              // [buf][c = 32][WD32_XP]: X^T of the row group
+  float* EO = XT + 2 * 32 * WD32_XP;                                // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const unsigned int* __restrict__ xb = p.xbits + z0 * p.xb_s0 + z1 * p.xb_s1;
+  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
+  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const int ncol0 = 32 * wave;
+
+  f32x4 bw[2][16];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int n = ncol0 + 16 * cb + li, k0 = 16 * t + 4 * lq;
+      const f32x4 t0 = *(const f32x4*)&wtg[k0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bw[cb][t][j] = t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
+    }
+  if (W0) for (int e = tid; e < 2 * 32 * WD32_XP; e += WS_NT) XT[e] = 0.f;      // rows c >= x_pitch are never written again
+  __syncthreads();
+
+  unsigned int sm_word;
+  float sx[2];
+  const int xe = W0 ? WS_ROWS * p.x_pitch : 0;
+  float* __restrict__ Cg = STORE ? p.C + z0 * p.c_s0 + z1 * p.c_s1 : nullptr;
+  int xo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    int rr = W0 ? e / (W0 ? p.x_pitch : 1) : 0, c = W0 ? e - rr * p.x_pitch : 0;
+    if (e >= xe) { rr = 32; c = 0; }                                 // pad slot, never read
+    xo[i] = ((c == p.in0) ? (1 << 16) : 0) | (c * WD32_XP + rr);
+  }
+  float sdq;
+  unsigned int sxw;
+  auto load_group = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    sdq = dqg[(long)(g * WS_ROWS + (tid & 31)) * p.dq_sm];
+    sxw = xb[(long)(g * WS_ROWS + ((tid >> 3) & 31)) * p.xb_g + (tid & 7)];
+    if (W0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int e = tid + WS_NT * i;
+        sx[i] = Xg[(long)g * xe + (e < xe ? e : xe - 1)];
+      }
+    }
+  };
+  auto store_group = [&](int buf) __attribute__((always_inline)) {
+    const int r = tid >> 4, hw = tid & 15;
+    const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
+    float* d = Am + (long)buf * WS_ROWS * WS_K + r * WS_K;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                    // chunk 4 hw + j = columns 16 hw + 4 j ..
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((bits >> (4 * j + e)) & 1u) ? 1.0f : 0.0f;
+      *(f32x4*)(d + (((4 * hw + j) ^ (r & 15)) << 2)) = v;
+    }
+    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
+    eo[tid & 31] = sdq;
+    ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
+    float* xt = XT + (long)buf * 32 * WD32_XP;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      if (W0) xt[xo[i] & 0xFFFF] = (xo[i] >> 16) ? 1.0f : sx[i];
+  };
+
+  f32x4 d2[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) d2[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 < p.groups) {
+    load_group(g0);
+    store_group(0);
+    if (g0 + gs < p.groups) load_group(g0 + gs);
+  }
+  __syncthreads();
+  auto iteration = [&](int g, int it) __attribute__((always_inline)) {
+    const int buf = it & 1;
+    const float* am = Am + (long)buf * WS_ROWS * WS_K;
+    f32x4 acc[WS_SUB][2];
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // (fenced per step: the scheduler otherwise hoists all 32 fragment reads of the unrolled loop to its top, 128 more live VGPRs
+    // next to the 128 of the resident weights; the SIMD's other wave covers the read latency)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      f32x4 fa[WS_SUB];
+#pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) fa[s] = *(const f32x4*)&am[(16 * s + li) * WS_K + (((4 * t + lq) ^ li) << 2)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int s = 0; s < WS_SUB; ++s)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)               // D[m][n]: lane holds rows 4 lq + r of column li
+            acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[s][e], bw[cb][t][e], acc[s][cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // epilogue operands of this group (staged with it): dq of the lane's 4 rows per 16-row block, the h0 mask word of those rows
+    const float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
+    const float* xt = XT + (long)buf * 32 * WD32_XP;
+#pragma unroll
+    for (int s = 0; s < WS_SUB; ++s) {
+      const f32x4 dq4s = *(const f32x4*)&eo[16 * s + 4 * lq];
+      const u32x4 xws = *(const u32x4*)&((const unsigned int*)eo)[WS_ROWS + wave * WS_ROWS + 16 * s + 4 * lq];
+      f32x4 xa[2];
+      if (W0) {
+#pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) xa[cbk] = *(const f32x4*)&xt[(16 * cbk + li) * WD32_XP + 16 * s + 4 * lq];
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = ((xws[r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4s[r] : 0.f;
+          if (STORE) Cg[(long)(g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + 16 * cb + li] = v[r];
+        }
+#pragma unroll
+        for (int cbk = 0; cbk < 2 && W0; ++cbk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[cbk][r], v[r], d2[cbk][cb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);             // one block at a time: interleaving the four blocks costs ~50 spilled VGPRs
+      }
+    }
+    if (g + gs < p.groups) store_group(buf ^ 1);
+    if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
+    __syncthreads();
+  };
+  int g = g0, it = 0;
+  for (; g < p.groups; g += gs, ++it) iteration(g, it);
+  if (!W0) return;
+  float* wo = p.w0_out + z0 * p.o_s0 + z1 * p.o_s1 + (long)blockIdx.x * p.o_ks;
+  float* bo = p.b0_out + z0 * p.o_s0 + z1 * p.ob_s1 + (long)blockIdx.x * p.o_ks;
+#pragma unroll
+  for (int cbk = 0; cbk < 2; ++cbk)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * cbk + 4 * lq + r, n = ncol0 + 16 * cb + li;
+        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r];
+        else if (c == p.in0) bo[n] = d2[cbk][cb][r];
+      }
+}
+
 hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
-  if (p.w0_out) hipLaunchKernelGGL((ws_dgrad_w0_kernel<true, false>), dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
-  else hipLaunchKernelGGL((ws_dgrad_w0_kernel<false, true>), dim3(per_z, 1, nz), dim3(WS_NT), ws_dgrad_lds_bytes(), st, p);
+  const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (p.f32) {
+    static const hipError_t attr_err = [] {
+      hipError_t e = hipFuncSetAttribute((const void*)ws_dgrad32_w0_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad32_lds_bytes());
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_dgrad32_w0_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad32_lds_bytes());
+      return e;
+    }();
+    if (attr_err != hipSuccess) return attr_err;
+    if (p.w0_out) hipLaunchKernelGGL((ws_dgrad32_w0_kernel<true, false>), grid, block, ws_dgrad32_lds_bytes(), st, p);
+    else hipLaunchKernelGGL((ws_dgrad32_w0_kernel<false, true>), grid, block, ws_dgrad32_lds_bytes(), st, p);
+    return hipGetLastError();
+  }
+  if (p.w0_out) hipLaunchKernelGGL((ws_dgrad_w0_kernel<true, false>), grid, block, ws_dgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL((ws_dgrad_w0_kernel<false, true>), grid, block, ws_dgrad_lds_bytes(), st, p);
   return hipGetLastError();
 }
 

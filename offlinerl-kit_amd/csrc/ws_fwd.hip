@@ -350,20 +350,19 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       if constexpr (F32) {
         // 32 k per step = two float4 chunks per lane and row block, 8 MFMA k steps x 4 accumulator blocks
         const float* af = Af + (long)buf * WS_ROWS * WS_K;
-        f32x4 fa[WS_SUB][2];
 #pragma unroll
-        for (int s = 0; s < WS_SUB; ++s)
+        for (int tt = 0; tt < 2; ++tt) {
+          f32x4 fa[WS_SUB];
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) fa[s][tt] = *(const f32x4*)&af[(16 * s + li) * WS_K + (((8 * ks + 4 * tt + lq) ^ li) << 2)];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+          for (int s = 0; s < WS_SUB; ++s) fa[s] = *(const f32x4*)&af[(16 * s + li) * WS_K + (((8 * ks + 4 * tt + lq) ^ li) << 2)];
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
               for (int cb = 0; cb < WS_CB; ++cb)
-                acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[cb][2 * ks + tt][e], fa[s][tt][e], acc[s][cb], 0, 0, 0);
+                acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[cb][2 * ks + tt][e], fa[s][e], acc[s][cb], 0, 0, 0);
+        }
       } else {
       bf16x8 fah2[WS_SUB], fal2[WS_SUB];
 #pragma unroll

@@ -142,6 +142,7 @@ struct WsDgradP {
   float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
   int M, nz1, groups;
+  int f32;                                                     // exact fp32 arithmetic (ws_dgrad32_w0_kernel) instead of split bf16
 };
 enum { WD_XP = WS_ROWS + 4 };                                       // bf16 pitch of an X^T row (72 B: scattered 2-byte stores and 8-byte reads spread over the banks)
 static constexpr size_t ws_dgrad_lds_bytes() {     // mask images + X^T images + per-group epilogue operands (dq, h0 mask words)
@@ -195,6 +196,7 @@ struct WsWgradP {
   const float* W1; long w1_s0, w1_s1;                          // [256][256] (out, in) row-major
   const float* b1; long b1_s0, b1_s1;
   int M, nz1, groups;
+  int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of split bf16
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
 static constexpr size_t ws_wgrad_lds_bytes() { return (size_t)2 * 3 * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2; }   // 2 buffers x {mask, G hi, G lo} + dq blocks

@@ -15,6 +15,95 @@ __device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
 }
 
+// Everything after the row loop, shared by the split-bf16 and the exact-fp32 kernel: the workgroup's split-K slab of dW1 / db1 and
+// the tail layer's gradients (streamed or derived).  `smem` = the kernel's LDS (the operand images are dead by now).
+template <int MODE>
+__device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, const f32x4 (&acc)[16][2], const f32x4 (&accb)[2], const f32x4& tacc,
+                                          const f32x4& bacc, float dqsum, const float* __restrict__ wtg, int z0, int z1, int ncol0) {
+  constexpr bool TAILS = (MODE == 1);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  // ---- one slab per workgroup ----
+  const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
+  float* dW = p.dW + so + z1 * p.o_s1w;
+  float* db = p.db + so + z1 * p.o_s1b;
+#pragma unroll
+  for (int kb = 0; kb < 16; ++kb) {
+    const f32x4 w4 = *(const f32x4*)&wtg[16 * kb + 4 * lq];           // lane holds rows k = 16 kb + 4 lq + r, column n = ncol0 + 16 nb + li
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
+  }
+  if (MODE == 2) {
+    // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
+    // group and then the 8 waves (= all 256 input columns) are summed in a fixed order
+    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
+    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 16 * kb + 4 * lq + r;
+        float t = W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r];
+        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+        if (li == 0) red[wave * WS_K + o] = t;
+      }
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r];
+    }
+    if (lane == 0) red[9 * WS_K + wave] = dqsum;
+    __syncthreads();
+    if (tid < WS_K) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[w * WS_K + tid];
+      const float gs1 = red[8 * WS_K + tid];
+      p.dwt[so + z1 * p.o_s1wt + tid] = a + (p.b1 + z0 * p.b1_s0 + z1 * p.b1_s1)[tid] * gs1;
+      db[tid] = wtg[tid] * gs1;
+    }
+    if (tid == 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[9 * WS_K + w];
+      p.dbt[so + z1 * p.o_s1bt] = a;
+    }
+    return;
+  }
+  if (!TAILS) {
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int k0 = 16 * (2 * wave + x) + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
+      }
+    }
+    return;
+  }
+  // TAILS: eight row-slice partial sums per column (threads tid, tid + 64, ...), summed in a fixed order
+  float* red = ws_smem;                                              // the images are dead after the loop's last barrier
+  *(f32x4*)&red[(tid >> 6) * WS_K + 4 * (tid & 63)] = tacc;
+  *(f32x4*)&red[(8 + (tid >> 6)) * WS_K + 4 * (tid & 63)] = bacc;
+  if ((tid & 63) == 0) red[16 * WS_K + (tid >> 6)] = dqsum;
+  __syncthreads();
+  if (tid < WS_K) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { a += red[w * WS_K + tid]; b += red[(8 + w) * WS_K + tid]; }
+    p.dwt[so + z1 * p.o_s1wt + tid] = a;
+    db[tid] = wtg[tid] * b;
+  }
+  if (tid == 0) {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a += red[16 * WS_K + w];
+    p.dbt[so + z1 * p.o_s1bt] = a;
+  }
+}
+
 template <int MODE>      // 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
@@ -184,86 +273,151 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
 
-  // ---- one slab per workgroup ----
-  const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
-  float* dW = p.dW + so + z1 * p.o_s1w;
-  float* db = p.db + so + z1 * p.o_s1b;
+  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0);
+}
+
+// ---- exact-fp32 flavour (precision 0): the same output-stationary structure on v_mfma_f32_16x16x4_f32 ----
+// A[i = k][kk = m] = mask[m][k] and B[kk = m][j = n] = G[m][n] are single floats per lane, read with ds_read_b32 from row-major fp32
+// images [32 rows][WW32_P]: a lane group lq reads 16 consecutive floats of row 4 step + lq, and the row pitch of 272 floats (16 mod 64
+// banks) puts the four rows of one read on disjoint banks.  32 rows = 8 MFMA k steps; two 16-row k blocks of the output are in flight
+// so that dependent MFMAs stay four instructions apart.
+enum { WW32_P = 272, WW32_IMG = WS_ROWS * WW32_P };
+static constexpr size_t ws_wgrad32_lds_bytes() { return sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS) > sizeof(float) * 17 * WS_K
+                                                        ? sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS) : sizeof(float) * 17 * WS_K; }
+
+template <int MODE>
+__global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
+  static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
+  constexpr bool TAILS = (MODE == 1);
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  float* img = ws_smem;                                             // [buf][{mask, G}][32][WW32_P]
+  float* dqs = img + 2 * 2 * WW32_IMG;                              // [buf][32]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ H0g = p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1;
+  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
+  const int ncol0 = 32 * wave;
+
+  f32x4 acc[16][2], accb[2];
 #pragma unroll
-  for (int kb = 0; kb < 16; ++kb) {
-    const f32x4 w4 = *(const f32x4*)&wtg[16 * kb + 4 * lq];           // lane holds rows k = 16 kb + 4 lq + r, column n = ncol0 + 16 nb + li
+  for (int kb = 0; kb < 16; ++kb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb) acc[kb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 s0[4];
+  f32x4 s1[TAILS ? 4 : 1];
+  f32x4 tacc = (f32x4){0.f, 0.f, 0.f, 0.f}, bacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dqsum = 0.f;
+  float sdq[4];
+  unsigned int sm_word;
+  auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    const long m = (long)g * WS_ROWS + r;
+    s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
+    if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
+    sdq[i] = dqg[m * p.dq_sm];
+  };
+  auto load_mask = [&](int g) __attribute__((always_inline)) {
+    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+  };
+  auto load_group = [&](int g) __attribute__((always_inline)) {
+    load_mask(g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
+    for (int i = 0; i < 4; ++i) load_piece(g, i);
+  };
+  auto store_mask = [&](int buf) __attribute__((always_inline)) {      // thread (row r, half-word hw): 16 mask bits -> 16 floats
+    float* mi = img + (long)buf * 2 * WW32_IMG;
+    const int r = tid >> 4, hw = tid & 15;
+    const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((bits >> (4 * j + e)) & 1u) ? 1.0f : 0.0f;
+      *(f32x4*)(mi + r * WW32_P + 16 * hw + 4 * j) = v;
+    }
+  };
+  auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
+    float* gi = img + (long)buf * 2 * WW32_IMG + WW32_IMG;
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    *(f32x4*)(gi + r * WW32_P + 4 * kq) = s0[i] * sdq[i];
+    if (TAILS) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { tacc[j] += sdq[i] * s1[i][j]; bacc[j] += s1[i][j] > 0.f ? sdq[i] : 0.f; }
+      dqsum += sdq[i];
+    } else if (kq == 0) {
+      dqs[buf * WS_ROWS + r] = sdq[i];
+      if (MODE == 2) dqsum += sdq[i];
+    }
+  };
+  auto store_group = [&](int buf) __attribute__((always_inline)) {
+    store_mask(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) store_piece(buf, i);
+  };
+
+  const int g0 = blockIdx.x, gs = gridDim.x;
+  if (g0 < p.groups) {
+    load_group(g0);
+    store_group(0);
+    if (g0 + gs < p.groups) load_group(g0 + gs);
   }
-  if (MODE == 2) {
-    // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
-    // group and then the 8 waves (= all 256 input columns) are summed in a fixed order
-    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
-    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * kb + 4 * lq + r;
-        float t = W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r];
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        if (li == 0) red[wave * WS_K + o] = t;
-      }
-    if (li == 0) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r];
-    }
-    if (lane == 0) red[9 * WS_K + wave] = dqsum;
-    __syncthreads();
-    if (tid < WS_K) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) a += red[w * WS_K + tid];
-      const float gs1 = red[8 * WS_K + tid];
-      p.dwt[so + z1 * p.o_s1wt + tid] = a + (p.b1 + z0 * p.b1_s0 + z1 * p.b1_s1)[tid] * gs1;
-      db[tid] = wtg[tid] * gs1;
-    }
-    if (tid == 0) {
-      float a = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) a += red[9 * WS_K + w];
-      p.dbt[so + z1 * p.o_s1bt] = a;
-    }
-    return;
-  }
-  if (!TAILS) {
-    if (li == 0) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int k0 = 16 * (2 * wave + x) + 4 * lq;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
-      }
-    }
-    return;
-  }
-  // TAILS: eight row-slice partial sums per column (threads tid, tid + 64, ...), summed in a fixed order
-  float* red = ws_smem;                                              // the images are dead after the loop's last barrier
-  *(f32x4*)&red[(tid >> 6) * WS_K + 4 * (tid & 63)] = tacc;
-  *(f32x4*)&red[(8 + (tid >> 6)) * WS_K + 4 * (tid & 63)] = bacc;
-  if ((tid & 63) == 0) red[16 * WS_K + (tid >> 6)] = dqsum;
   __syncthreads();
-  if (tid < WS_K) {
-    float a = 0.f, b = 0.f;
+  auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
+    const int buf = it & 1;
+    const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
+    const float* mi = img + (long)buf * 2 * WW32_IMG;
+    const float* gi = mi + WW32_IMG;
+    const float* dqb = dqs + buf * WS_ROWS;
+    const int ro = lq * WW32_P + li;                                  // row 4 step + lq, column (block) + li
+    float bg[2][8], bd[8];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) { a += red[w * WS_K + tid]; b += red[(8 + w) * WS_K + tid]; }
-    p.dwt[so + z1 * p.o_s1wt + tid] = a;
-    db[tid] = wtg[tid] * b;
-  }
-  if (tid == 0) {
-    float a = 0.f;
+    for (int st = 0; st < 8; ++st) {
 #pragma unroll
-    for (int w = 0; w < 8; ++w) a += red[16 * WS_K + w];
-    p.dbt[so + z1 * p.o_s1bt] = a;
-  }
+      for (int nb = 0; nb < 2; ++nb) bg[nb][st] = gi[4 * st * WW32_P + ro + ncol0 + 16 * nb];
+      if (!TAILS) { const float d = dqb[4 * st + lq]; bd[st] = li == 0 ? d : 0.f; }
+    }
+#pragma unroll
+    for (int kp = 0; kp < 8; ++kp) {
+      const int kb0 = 2 * kp, kb1 = kb0 + 1;
+      float a0[8], a1[8];
+#pragma unroll
+      for (int st = 0; st < 8; ++st) { a0[st] = mi[4 * st * WW32_P + ro + 16 * kb0]; a1[st] = mi[4 * st * WW32_P + ro + 16 * kb1]; }
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[st], bg[nb][st], acc[kb0][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[st], bg[nb][st], acc[kb1][nb], 0, 0, 0);
+      }
+      if (!TAILS && kp == 7) {                                        // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
+        float c0[8], c1[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) { c0[st] = mi[4 * st * WW32_P + ro + 32 * wave]; c1[st] = mi[4 * st * WW32_P + ro + 32 * wave + 16]; }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+          accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[st], bd[st], accb[0], 0, 0, 0);
+          accb[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[st], bd[st], accb[1], 0, 0, 0);
+        }
+      }
+      if (kp < 4) {
+        if (more) store_piece(buf ^ 1, kp);
+        if (more2) load_piece(g + 2 * gs, kp);
+      }
+      if (kp == 5) {
+        if (more) store_mask(buf ^ 1);
+        if (more2) load_mask(g + 2 * gs);
+      }
+    }
+    __syncthreads();
+  };
+  int g = g0, it = 0;
+  for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);
+  for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
+  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0);
 }
 
 hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
@@ -272,12 +426,22 @@ hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
-  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<1>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
-  else if (p.W1) hipLaunchKernelGGL(ws_wgrad_kernel<2>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
-  else hipLaunchKernelGGL(ws_wgrad_kernel<0>, dim3(per_z, 1, nz), dim3(WS_NT), ws_wgrad_lds_bytes(), st, p);
+  const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (p.f32) {
+    if (p.H1) hipLaunchKernelGGL(ws_wgrad32_kernel<1>, grid, block, ws_wgrad32_lds_bytes(), st, p);
+    else if (p.W1) hipLaunchKernelGGL(ws_wgrad32_kernel<2>, grid, block, ws_wgrad32_lds_bytes(), st, p);
+    else hipLaunchKernelGGL(ws_wgrad32_kernel<0>, grid, block, ws_wgrad32_lds_bytes(), st, p);
+    return hipGetLastError();
+  }
+  if (p.H1) hipLaunchKernelGGL(ws_wgrad_kernel<1>, grid, block, ws_wgrad_lds_bytes(), st, p);
+  else if (p.W1) hipLaunchKernelGGL(ws_wgrad_kernel<2>, grid, block, ws_wgrad_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_wgrad_kernel<0>, grid, block, ws_wgrad_lds_bytes(), st, p);
   return hipGetLastError();
 }
 

@@ -157,27 +157,30 @@ def test_cql_bench_sized_engine_follows_the_oracle(R):
         eng.close()
 
 
-def test_cql_derived_tail_gradients_match_streamed_ones(monkeypatch):
+@pytest.mark.parametrize("precision", [1, 0])
+def test_cql_derived_tail_gradients_match_streamed_ones(monkeypatch, precision):
     """The engine normally keeps the critics' top hidden activation h1 out of HBM (mask bits only) and derives
     dw_tail = sum_k W1[n][k] G[n][k] + b1[n] g[n] from the wgrad accumulators; ORL_WS_KEEP_H1=1 stores h1 and streams it for
-    dw_tail = sum_m dq[m] h1[m][n].  Same inputs -> same losses and same updated tail parameters to rounding."""
+    dw_tail = sum_m dq[m] h1[m][n].  Same inputs -> same losses and same updated tail parameters to rounding (split-bf16
+    kernels and their exact-fp32 flavours ws_fwd_kernel<..., F32> / ws_wgrad32_kernel<1 | 2>)."""
     case = "cql_halfcheetah"
     R = 4
-    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=1)
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
     monkeypatch.setenv("ORL_WS_KEEP_H1", "1")
-    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=1)
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=precision)
     monkeypatch.delenv("ORL_WS_KEEP_H1")
+    loss_bar, mean_bar, frac_bar = ((2e-5, 3e-6, 2e-3) if precision == 1 else (2e-6, 3e-7, 3e-4))
     try:
         for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
             ma = enga.step(lead(b, R), lead(noise_list(n), R))
             mb = engb.step(lead(b, R), lead(noise_list(n), R))
-            assert rel_err(ma[R - 1], mb[R - 1], floor=1e-2) < 2e-5, (k, ma[R - 1], mb[R - 1])
+            assert rel_err(ma[R - 1], mb[R - 1], floor=1e-2) < loss_bar, (k, ma[R - 1], mb[R - 1])
         for nm in ("critic1", "critic2"):
             a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
             for pn in a:
                 d = np.abs(a[pn] - b1[pn])
-                assert d.mean() < 3e-6, (nm, pn, d.mean())
-                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < 2e-3, (nm, pn)
+                assert d.mean() < mean_bar, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < frac_bar, (nm, pn)
     finally:
         enga.close(); engb.close()
 
@@ -209,10 +212,11 @@ def test_cql_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
         eng4.close(); eng1.close()
 
 
-def test_cql_fp32_weight_stationary_forward_matches_tiled_kernels(monkeypatch):
-    """Exact fp32, full size: the weight-stationary forward's fp32 variant (ws_fwd_kernel<..., F32 = true>: v_mfma_f32_16x16x4_f32,
-    fused first layer, fused tail, mask bits, plain-dgrad mode) against an engine created with ORL_WS32=0, which keeps precision 0
-    on the tiled fp32 kernels.  Same inputs, both exact fp32 products with fp32 accumulation in a different summation order ->
+def test_cql_fp32_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
+    """Exact fp32, full size: the fp32 flavours of the weight-stationary forward (ws_fwd_kernel<..., F32 = true>:
+    v_mfma_f32_16x16x4_f32, fused first layer, fused tail, mask bits, plain-dgrad mode, top activation not stored) and of the
+    output-stationary wgrad with derived tail gradients (ws_wgrad32_kernel<2>) against an engine created with ORL_WS32=0, which
+    keeps precision 0 on the tiled fp32 kernels.  Same inputs, both exact fp32 products with fp32 accumulation in a different summation order ->
     losses agree to a few ulps of the reductions, updated parameters to Adam's sensitivity at near-zero gradients."""
     case = "cql_halfcheetah"
     R = 4
