@@ -47,9 +47,19 @@ def grad_err(got, ref):
     return float(np.abs(got - ref).max() / scale), float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
 
 
-def check_grads(eng, run, net_id, ref, tag, precision=1, report=None):
+# Exact fp32 on the THREE-layer nets (CQL [256,256,256], EDAC) against the fp32 numpy oracle: both sides are fp32 sums in different
+# orders.  A ReLU whose pre-activation is within an ulp of zero comes out on the other side and moves one whole term of every
+# gradient below it, and EDAC's gradient-diversity term is a difference of large sums (the double-backward sweep), so fp32-vs-fp32
+# summation noise shows at 1e-4 .. 1e-3 of the tensor scale.  Measured worst tensors: CQL h3 5.4e-4 max / 3.9e-4 relative L2, EDAC
+# 4.2e-3 / 4.2e-4 (1.7 % of a 256 x 256 layer's elements above 1e-4 of the scale) -- digit for digit the same on the tiled fp32 kernels
+# (ORL_WS32=0) and on the weight-stationary fp32 kernels (tools/grad_report_algo.py), i.e. a property of the comparison with an fp32
+# oracle, not of a kernel; two-layer CQL / IQL / TD3+BC meet the plain fp32 bars (2.6e-5, 7.6e-7, 7.6e-7).
+BARS_FP32_3LAYER = (1e-2, 1e-3)
+
+
+def check_grads(eng, run, net_id, ref, tag, precision=1, report=None, bars=None):
     got = eng.debug_grads(run, net_id)
-    bar_max, bar_l2 = BARS[precision]
+    bar_max, bar_l2 = bars or BARS[precision]
     for name, g in ref.items():
         if "saved_" in name:
             continue
@@ -154,15 +164,18 @@ def check_params(eng, runs, nets, st, steps, tag, init=None, rel_bar=5e-2):
                         assert rel < rel_bar, (tag, r, nm, pn, "deviation / update (L2)", rel)
 
 
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("R", [96, 128])
-def test_cql_bench_configuration_gradients_and_parameters(R):
-    """CQL, halfcheetah shapes, split-bf16, R = 96 (bench.py's engine: 192 batched critics, 192 of 256 CUs) and 128 (256 critics):
+def test_cql_bench_configuration_gradients_and_parameters(R, precision):
+    """(precision 0: the exact-fp32 flavours of the same kernels -- ws_fwd_kernel<..., F32>, ws_dgrad32_w0_kernel, ws_wgrad32_kernel<2>
+    and, for the 256-row phases of >= 16 runs, the fp32 plain-dgrad / storing variants -- against the fp32 bars.)
+    CQL, halfcheetah shapes, split-bf16, R = 96 (bench.py's engine: 192 batched critics, 192 of 256 CUs) and 128 (256 critics):
     every gradient tensor of actor / critic1 / critic2 of the first, middle and last run against the oracle for two consecutive
     steps (the second step starts from Adam-updated parameters and targets), then the parameters after three steps.  Gradient bars:
     module docstring, check (2); from the second step on both sides start from parameters that already differ by Adam's
     sign-like first update on the few elements whose tiny gradients disagree, so only losses / parameters are compared there."""
     from oracle import cql as ocql
-    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah", n_runs=R, precision=1)
+    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah", n_runs=R, precision=precision)
     runs = (0, R // 2, R - 1)
     init = clone_state({k: st[k] for k in ("actor", "critic1", "critic2")})
     try:
@@ -175,19 +188,20 @@ def test_cql_bench_configuration_gradients_and_parameters(R):
                 assert tc.rel_err(m[r], ora, floor=1e-2) < 1e-4, (k, r, m[r], ora)
                 if k == 0:
                     for nm in ("actor", "critic1", "critic2"):
-                        check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], (R, k, r, nm), 1, report)
-        print(f"CQL R={R} split-bf16, step-0 gradients vs oracle: worst max/scale {max(x[2] for x in report):.2e}, worst rel L2 {max(x[3] for x in report):.2e}")
+                        check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], (R, k, r, nm), precision, report)
+        print(f"CQL R={R} precision {precision}, step-0 gradients vs oracle: worst max/scale {max(x[2] for x in report):.2e}, worst rel L2 {max(x[3] for x in report):.2e}")
         check_params(eng, runs, {nm: tc.NETS[nm] for nm in ("actor", "critic1", "critic2", "critic1_old", "critic2_old")}, st, 3, ("cql", R), init)
     finally:
         eng.close()
 
 
-def test_cql_three_layer_gradients():
+@pytest.mark.parametrize("precision", [1, 0])
+def test_cql_three_layer_gradients(precision):
     """reference CLI default [256,256,256] (run_cql.py:31): the middle layers go through the plain weight-stationary dgrad and the
-    tiled wgrads; 32 runs, split-bf16"""
+    tiled wgrads; 32 runs, split-bf16 and exact fp32"""
     from oracle import cql as ocql
     R = 32
-    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=1)
+    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=precision)
     init = clone_state({k: st[k] for k in ("actor", "critic1", "critic2")})
     try:
         for k, (b, n) in enumerate(zip(batches[:2], noises[:2])):
@@ -195,7 +209,7 @@ def test_cql_three_layer_gradients():
             eng.step(tc.lead(b, R), tc.lead(tc.noise_list(n), R))
             for r in ((0, R - 1) if k == 0 else ()):
                 for nm in ("actor", "critic1", "critic2"):
-                    check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], ("h3", k, r, nm), 1)
+                    check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], ("h3", k, r, nm), precision, bars=BARS_FP32_3LAYER if precision == 0 else None)
         check_params(eng, (0, R - 1), {nm: tc.NETS[nm] for nm in ("actor", "critic1", "critic2")}, st, 2, "cql_h3", init, rel_bar=0.15)     # measured 8.2 % (one top-layer mask flip reaches both layers below)
     finally:
         eng.close()
@@ -208,14 +222,15 @@ GRAD_NETS = {
 }
 
 
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
-def test_other_algorithms_gradients_and_parameters_at_128_runs(algo):
-    """IQL / TD3+BC / EDAC at 128 runs per engine in split-bf16 (full-size fixtures' shapes): gradients of every trainable net at
+def test_other_algorithms_gradients_and_parameters_at_128_runs(algo, precision):
+    """IQL / TD3+BC / EDAC at 128 runs per engine in split-bf16 and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
     step 0, losses for three steps, parameters after three.  TD3+BC's actor only steps on even counts (td3bc.py:107): its gradient is
     compared on those steps."""
     R = 128
     case = ta._full_size_case(algo)
-    eng, mod, cfg, st, batches, noises = ta.make_engine(algo, case, n_runs=R, precision=1)
+    eng, mod, cfg, st, batches, noises = ta.make_engine(algo, case, n_runs=R, precision=precision)
     ids = ta.NET_IDS[algo]
     runs = (0, R // 2, R - 1)
     report = []
@@ -232,8 +247,9 @@ def test_other_algorithms_gradients_and_parameters_at_128_runs(algo):
                 if k == 0:
                     for nm in GRAD_NETS[algo]:
                         if nm + "_grads" in aux:
-                            check_grads(eng, r, ids[nm], aux[nm + "_grads"], (algo, k, r, nm), 1, report)
-        print(f"{algo} R={R} split-bf16, step-0 gradients vs oracle: worst max/scale {max(x[2] for x in report):.2e}, worst rel L2 {max(x[3] for x in report):.2e}")
+                            check_grads(eng, r, ids[nm], aux[nm + "_grads"], (algo, k, r, nm), precision, report,
+                                        bars=BARS_FP32_3LAYER if (precision == 0 and algo == "edac") else None)
+        print(f"{algo} R={R} precision {precision}, step-0 gradients vs oracle: worst max/scale {max(x[2] for x in report):.2e}, worst rel L2 {max(x[3] for x in report):.2e}")
         trainable = {nm: ids[nm] for nm in ids}
         st_cmp = {nm: ta._strip_saved(st[nm]) for nm in trainable}
         check_params(eng, runs, trainable, st_cmp, 3, algo, init)
