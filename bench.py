@@ -356,7 +356,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or drop WORLD_SIZE")
     if args.launch_check:
-        print("LAUNCH " + json.dumps(dict(rank=rank, local_rank=local_rank, world=world, gpus=args.gpus)), flush=True)
+        # one write(2) per rank: the ranks share the parent's stdout, and a text-mode print may split the line and its newline
+        sys.stdout.flush()
+        os.write(1, ("LAUNCH " + json.dumps(dict(rank=rank, local_rank=local_rank, world=world, gpus=args.gpus)) + "\n").encode())
         return
     preset = PRESETS.get(args.preset, {})
     R = args.runs_per_gpu if args.runs_per_gpu is not None else int(os.environ.get("ORL_RUNS_PER_GPU", preset.get("runs_per_gpu", 96)))

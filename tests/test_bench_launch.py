@@ -3,6 +3,7 @@ RANK / LOCAL_RANK / WORLD_SIZE, started before anything touches the GPU; a misma
 itself needs MI355Xs; `--launch-check` makes every rank report its environment and exit.)"""
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -20,7 +21,7 @@ def test_gpus_flag_starts_one_rank_per_gpu():
     p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check", "--preset", "config5"], capture_output=True, text=True,
                        timeout=300, env=_env())
     assert p.returncode == 0, p.stderr[-2000:]
-    ranks = [json.loads(ln[len("LAUNCH "):]) for ln in p.stdout.splitlines() if ln.startswith("LAUNCH ")]
+    ranks = [json.loads(m) for m in re.findall(r"LAUNCH (\{[^}]*\})", p.stdout)]      # (robust to two ranks' lines sharing one pipe)
     assert sorted(r["rank"] for r in ranks) == [0, 1]
     assert sorted(r["local_rank"] for r in ranks) == [0, 1]
     assert all(r["world"] == 2 and r["gpus"] == 2 for r in ranks)
