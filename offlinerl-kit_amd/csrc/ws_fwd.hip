@@ -304,7 +304,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
   f32x4 pacc[WS_SUB][WS_CB];
   // steady = true: groups g + gs .. g + 3 gs exist, so the body has no conditionals (one basic block up to the barrier)
-  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady, bool lead = false) __attribute__((always_inline)) {
+  auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
     const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
     const __bf16* al = ah + WS_ROWS * WS_PITCH;
@@ -339,11 +339,6 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     };
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      // `lead` (the second wave of each SIMD, waves 4..7): the piece runs BEFORE the step's MFMAs instead of behind them.  The two
-      // waves of a SIMD execute the same program between the same barriers; in step their MFMA bursts collide on the one matrix
-      // pipe and their VALU pieces on the one vector ALU, and the pipe idles half the time (PMC: 50 % busy).  Out of step, one
-      // wave's vector work runs under the other's matrix work.
-      if (fine && lead) { piece(ks); __builtin_amdgcn_sched_barrier(0); }
       // the three products of a block are issued plane by plane (lo*hi, hi*lo, hi*hi over all four blocks) so that dependent MFMAs
       // on one accumulator are four instructions apart; operands swapped: D[n][m], lane holds C[m = li][n = 4 lq + r]
       // (fetching the fragments one k step ahead, behind the MFMAs that free their registers, measured no different: r02 A/B)
@@ -384,7 +379,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
         for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
       }
       if (fine) {
-        if (!lead) piece(ks);
+        piece(ks);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -413,14 +408,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   int g = g0, it = 0;
   iteration(g, it, st0, true, false);
   g += gs; ++it;
-#ifdef ORL_WS_STAGGER
-  const bool second_half = __builtin_amdgcn_readfirstlane(wave) >= WS_NW / 2;       // wave w and w + 4 share a SIMD
-#else
-  const bool second_half = false;
-#endif
   while (g + 3 * gs < p.groups) {
-    if (second_half) iteration(g, it, st0, false, true, true);
-    else iteration(g, it, st0, false, true, false);
+    iteration(g, it, st0, false, true);
     g += gs; ++it;
   }
   while (g < p.groups) {
