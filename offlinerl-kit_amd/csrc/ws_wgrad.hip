@@ -5,6 +5,8 @@ namespace orl {
 
 // bf16 offset of the 8-byte piece (16-byte chunk `chunk`, half `half`) of row r: chunks are XOR-swizzled with 2 (r & 7) so that
 // the transposed reads (8 rows x 32 B per 32-lane half) and the 8-byte staging stores are both bank-conflict free
+// (a padded row pitch of 272 elements instead of the swizzle makes every fragment address lane part + immediate, but measured 2 %
+// slower at 128 runs: 581 vs 569 us)
 __device__ inline int ww_off(int r, int chunk, int half) { return r * WS_K + ((chunk ^ (2 * (r & 7))) << 3) + (half << 2); }
 
 __device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
@@ -134,26 +136,25 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   float sdq[4];
   unsigned int sm_word;
   __bf16* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
-  auto load_group = [&](int g) __attribute__((always_inline)) {
-    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
-      const long m = (long)g * WS_ROWS + r;
-      s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
-      if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
-      sdq[i] = dqg[m * p.dq_sm];
-    }
-  };
+  // Global addresses = (uniform part: row group and piece, scalar ALU) + (per-thread part, computed once): the loop carries no vector
+  // address arithmetic (64-bit multiplies cost a SIMD 4 - 7 cycles each, and vector instructions do not overlap with its MFMAs).
+  const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
+  const unsigned int vo_h1 = TAILS ? (unsigned int)((tid >> 6) * p.h1_pitch + 4 * (tid & 63)) : 0u;
+  const unsigned int vo_dq = (unsigned int)((tid >> 6) * (int)p.dq_sm);
+  const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
-    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
-    const long m = (long)g * WS_ROWS + r;
-    s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
-    if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
-    sdq[i] = dqg[m * p.dq_sm];
+    const long row0 = (long)g * WS_ROWS + 8 * i;                      // uniform: rows row0 + (tid >> 6)
+    s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
+    if (TAILS) s1[i] = *(const f32x4*)&(H1g + row0 * p.h1_pitch)[vo_h1];
+    sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
   auto load_mask = [&](int g) __attribute__((always_inline)) {
-    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
+  };
+  auto load_group = [&](int g) __attribute__((always_inline)) {
+    load_mask(g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_piece(g, i);
   };
   auto store_mask = [&](int buf) __attribute__((always_inline)) {
     __bf16* mi = img + (long)buf * 3 * WW_IMG;
@@ -313,15 +314,19 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   float dqsum = 0.f;
   float sdq[4];
   unsigned int sm_word;
+  // (uniform part of every global address on the scalar ALU, per-thread part computed once: see ws_wgrad_kernel)
+  const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
+  const unsigned int vo_h1 = TAILS ? (unsigned int)((tid >> 6) * p.h1_pitch + 4 * (tid & 63)) : 0u;
+  const unsigned int vo_dq = (unsigned int)((tid >> 6) * (int)p.dq_sm);
+  const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
-    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
-    const long m = (long)g * WS_ROWS + r;
-    s0[i] = *(const f32x4*)&H0g[m * p.h0_pitch + 4 * kq];
-    if (TAILS) s1[i] = *(const f32x4*)&H1g[m * p.h1_pitch + 4 * kq];
-    sdq[i] = dqg[m * p.dq_sm];
+    const long row0 = (long)g * WS_ROWS + 8 * i;
+    s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
+    if (TAILS) s1[i] = *(const f32x4*)&(H1g + row0 * p.h1_pitch)[vo_h1];
+    sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
   auto load_mask = [&](int g) __attribute__((always_inline)) {
-    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
   };
   auto load_group = [&](int g) __attribute__((always_inline)) {
     load_mask(g);
