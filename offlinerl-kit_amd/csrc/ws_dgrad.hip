@@ -57,18 +57,22 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   }
   float sdq;
   unsigned int sxw;
+  // global addresses = scalar row-group base + per-thread offset computed once (no 64-bit vector multiplies in the loop)
+  const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1)), vo_dq = (unsigned int)((tid & 31) * (int)p.dq_sm);
+  const unsigned int vo_xb = (unsigned int)(((tid >> 3) & 31) * p.xb_g + (tid & 7));
+  unsigned int vo_x[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; vo_x[i] = (unsigned int)(e < xe ? e : (xe > 0 ? xe - 1 : 0)); }   // clamped, not predicated
   auto load_group = [&](int g) __attribute__((always_inline)) {
-    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
+    const long row0 = (long)g * WS_ROWS;
+    sm_word = (ab + row0 * p.ab_g)[vo_ab];
     // the epilogue's dq and h0 mask words travel through LDS with the group (fetched a full iteration ahead by the staging threads:
     // the epilogue then has no global loads of its own to wait for)
-    sdq = dqg[(long)(g * WS_ROWS + (tid & 31)) * p.dq_sm];
-    sxw = xb[(long)(g * WS_ROWS + ((tid >> 3) & 31)) * p.xb_g + (tid & 7)];
+    sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    sxw = (xb + row0 * p.xb_g)[vo_xb];
     if (W0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + WS_NT * i;
-        sx[i] = Xg[(long)g * xe + (e < xe ? e : xe - 1)];              // clamped, not predicated
-      }
+      for (int i = 0; i < 2; ++i) sx[i] = (Xg + (long)g * xe)[vo_x[i]];
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
@@ -254,16 +258,19 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
   }
   float sdq;
   unsigned int sxw;
-  auto load_group = [&](int g) __attribute__((always_inline)) {
-    sm_word = ab[(long)(g * WS_ROWS + (tid >> 4)) * p.ab_g + ((tid & 15) >> 1)];
-    sdq = dqg[(long)(g * WS_ROWS + (tid & 31)) * p.dq_sm];
-    sxw = xb[(long)(g * WS_ROWS + ((tid >> 3) & 31)) * p.xb_g + (tid & 7)];
+  const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1)), vo_dq = (unsigned int)((tid & 31) * (int)p.dq_sm);
+  const unsigned int vo_xb = (unsigned int)(((tid >> 3) & 31) * p.xb_g + (tid & 7));
+  unsigned int vo_x[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; vo_x[i] = (unsigned int)(e < xe ? e : (xe > 0 ? xe - 1 : 0)); }
+  auto load_group = [&](int g) __attribute__((always_inline)) {      // scalar row-group base + per-thread offset (see ws_dgrad_w0_kernel)
+    const long row0 = (long)g * WS_ROWS;
+    sm_word = (ab + row0 * p.ab_g)[vo_ab];
+    sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    sxw = (xb + row0 * p.xb_g)[vo_xb];
     if (W0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = tid + WS_NT * i;
-        sx[i] = Xg[(long)g * xe + (e < xe ? e : xe - 1)];
-      }
+      for (int i = 0; i < 2; ++i) sx[i] = (Xg + (long)g * xe)[vo_x[i]];
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
