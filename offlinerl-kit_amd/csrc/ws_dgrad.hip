@@ -10,6 +10,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
   __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
   float* EO = (float*)(XT + 2 * 2 * 32 * WD_XP);                   // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]: epilogue operands
+  __shared__ u32x2_t mlut[16];                                     // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     }
   // zero both X^T images once (rows c >= x_pitch are never written again)
   if (W0) for (int e = tid; e < 2 * 2 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
+  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * 0x3F80u, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * 0x3F80u};
   __syncthreads();
 
   // ---- staging of one row group: thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
@@ -79,12 +81,10 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     u32x4 c0, c1;                                                    // 16 bf16 values: 1.0 = 0x3F80 where the bit is set
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned int y0 = (bits >> (2 * j)) & 3u, y1 = (bits >> (8 + 2 * j)) & 3u;
-      c0[j] = ((y0 & 1u) | ((y0 >> 1) << 16)) * 0x3F80u;
-      c1[j] = ((y1 & 1u) | ((y1 >> 1) << 16)) * 0x3F80u;
-    }
+    // through a 16-entry LDS table (4 bits -> 4 bf16): four LDS reads instead of ~32 vector instructions (see ws_wgrad_kernel)
+    const u32x2_t q0 = mlut[bits & 15u], q1 = mlut[(bits >> 4) & 15u], q2 = mlut[(bits >> 8) & 15u], q3 = mlut[bits >> 12];
+    c0 = (u32x4){q0[0], q0[1], q1[0], q1[1]};
+    c1 = (u32x4){q2[0], q2[1], q3[0], q3[1]};
     __bf16* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
   float* Am = ws_smem;                                              // [buf][row][256] 0/1 mask as fp32, swizzled
   float* XT = Am + 2 * WS_ROWS * WS_K;                              // [buf][c = 32][WD32_XP]: X^T of the row group
   float* EO = XT + 2 * 32 * WD32_XP;                                // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]
+  __shared__ f32x4 mlut32[16];                                      // 4 mask bits -> 4 floats (0.0 / 1.0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
       for (int j = 0; j < 4; ++j) bw[cb][t][j] = t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
     }
   if (W0) for (int e = tid; e < 2 * 32 * WD32_XP; e += WS_NT) XT[e] = 0.f;      // rows c >= x_pitch are never written again
+  if (tid < 16) mlut32[tid] = (f32x4){(float)(tid & 1), (float)((tid >> 1) & 1), (float)((tid >> 2) & 1), (float)(tid >> 3)};
   __syncthreads();
 
   unsigned int sm_word;
@@ -278,12 +280,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     float* d = Am + (long)buf * WS_ROWS * WS_K + r * WS_K;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                                    // chunk 4 hw + j = columns 16 hw + 4 j ..
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ((bits >> (4 * j + e)) & 1u) ? 1.0f : 0.0f;
-      *(f32x4*)(d + (((4 * hw + j) ^ (r & 15)) << 2)) = v;
-    }
+    for (int j = 0; j < 4; ++j)                                      // chunk 4 hw + j = columns 16 hw + 4 j ..; 4 bits -> 4 floats: LDS table
+      *(f32x4*)(d + (((4 * hw + j) ^ (r & 15)) << 2)) = mlut32[(bits >> (4 * j)) & 15u];
     float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
     eo[tid & 31] = sdq;
     ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;

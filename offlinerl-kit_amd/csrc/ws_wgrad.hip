@@ -112,6 +112,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   constexpr bool TAILS = (MODE == 1);
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   __bf16* img = (__bf16*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
+  __shared__ u32x2_t mlut[16];                                      // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -161,12 +162,11 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     u32x4 c0, c1;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned int y0 = (bits >> (2 * j)) & 3u, y1 = (bits >> (8 + 2 * j)) & 3u;
-      c0[j] = ((y0 & 1u) | ((y0 >> 1) << 16)) * 0x3F80u;
-      c1[j] = ((y1 & 1u) | ((y1 >> 1) << 16)) * 0x3F80u;
-    }
+    // 4 bits -> 4 bf16 (0.0 / 1.0) through a 16-entry LDS table: four LDS reads instead of ~32 vector instructions per thread and group
+    // (vector instructions and MFMAs of a SIMD do not overlap; the LDS pipe has room)
+    const u32x2_t q0 = mlut[bits & 15u], q1 = mlut[(bits >> 4) & 15u], q2 = mlut[(bits >> 8) & 15u], q3 = mlut[bits >> 12];
+    c0 = (u32x4){q0[0], q0[1], q1[0], q1[1]};
+    c1 = (u32x4){q2[0], q2[1], q3[0], q3[1]};
     *(u32x4*)(mi + ww_off(r, 2 * hw, 0)) = c0;
     *(u32x4*)(mi + ww_off(r, 2 * hw + 1, 0)) = c1;
   };
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
   if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
+  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * 0x3F80u, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * 0x3F80u};
   __syncthreads();
 
   const int g0 = blockIdx.x, gs = gridDim.x;
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   float* img = ws_smem;                                             // [buf][{mask, G}][32][WW32_P]
   float* dqs = img + 2 * 2 * WW32_IMG;                              // [buf][32]
+  __shared__ f32x4 mlut[16];                                        // 4 mask bits -> 4 floats (0.0 / 1.0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
@@ -338,12 +340,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = ((bits >> (4 * j + e)) & 1u) ? 1.0f : 0.0f;
-      *(f32x4*)(mi + r * WW32_P + 16 * hw + 4 * j) = v;
-    }
+    for (int j = 0; j < 4; ++j) *(f32x4*)(mi + r * WW32_P + 16 * hw + 4 * j) = mlut[(bits >> (4 * j)) & 15u];      // 4 bits -> 4 floats: LDS table
   };
   auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
     float* gi = img + (long)buf * 2 * WW32_IMG + WW32_IMG;
@@ -364,6 +361,8 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
 
+  if (threadIdx.x < 16) mlut[threadIdx.x] = (f32x4){(float)(threadIdx.x & 1u), (float)((threadIdx.x >> 1) & 1u), (float)((threadIdx.x >> 2) & 1u), (float)(threadIdx.x >> 3)};
+  __syncthreads();
   const int g0 = blockIdx.x, gs = gridDim.x;
   if (g0 < p.groups) {
     load_group(g0);
