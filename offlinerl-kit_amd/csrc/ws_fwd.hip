@@ -143,9 +143,22 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
   };
+  // Split-bf16: the narrow rows are split ONCE here, by the two staging threads of an element, into a hi plane (bf16 slots 0..31 of
+  // the 144-byte row) and a lo plane (slots 32..63) -- not by every wave in prod_x (eight times the same 32 vector instructions per
+  // group, and vector instructions do not overlap with a SIMD's MFMAs).  Surplus threads write the pad slots 64 / 65.
   auto storeX = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];   // surplus threads: pad column 32
+    for (int i = 0; i < 2; ++i) {
+      const float x = (xc[i] == p.in0) ? 1.0f : sx[i];
+      if constexpr (F32) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = x;   // surplus threads: pad column 32
+      else {
+        __bf16* row = (__bf16*)(Xl + (buf * WS_ROWS + xr[i]) * WS_XLP);
+        const bool pad = xc[i] >= 32;
+        const __bf16 hh = (__bf16)x;
+        row[pad ? 64 : xc[i]] = hh;
+        row[pad ? 65 : 32 + xc[i]] = (__bf16)(x - (float)hh);
+      }
+    }
   };
   // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
   f32x4 fx32[2];                                     // F32: the narrow-input fragments of prod_x (k = 16 t + 4 lq + e)
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 4 * lq;
       fx32[0] = *(const f32x4*)xrow; fx32[1] = *(const f32x4*)(xrow + 16);
     } else {
-      const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 8 * lq;
-      ws_split8(*(const f32x4*)xrow, *(const f32x4*)(xrow + 4), xah, xal);
+      const __bf16* xrow = (const __bf16*)(Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP) + 8 * lq;
+      xah = *(const bf16x8*)xrow; xal = *(const bf16x8*)(xrow + 32);
     }
   };
   auto prod_block = [&](int g, int buf, int par, int s, int cb, const bf16x8& xah, const bf16x8& xal) __attribute__((always_inline)) {
