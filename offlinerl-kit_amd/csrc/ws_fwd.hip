@@ -187,8 +187,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
       v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+    const unsigned int nib0 = orl_relu_mask4(v);
     const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
     *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
     if constexpr (F32) {
@@ -200,8 +199,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     *(bf16x4*)(dh + o) = h;
     *(bf16x4*)(dl + o) = l;
     }
-    nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] =
-        (unsigned char)orl_mask4(v);
+    nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] = (unsigned char)nib0;
   };
   auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
 #pragma unroll
@@ -253,13 +251,11 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     const f32x4 bq = *(const f32x4*)&cst[ncol0 + 16 * cb + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol0 + 16 * cb + 4 * lq];
     const int m = g * WS_ROWS + 16 * s + li;
     f32x4 v = a + bq;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+    const unsigned int nib = orl_relu_mask4(v);
     if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
     part += (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
     // 4 mask bits of (row 16 s + li, columns ncol0 + 16 cb + 4 lq ..) -> LDS, packed into words after the barrier
-    nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] =
-        (unsigned char)orl_mask4(v);
+    nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * WS_CB * wave + 4 * cb + lq] = (unsigned char)nib;
   };
   auto epi_row = [&](int par, int s, float part) __attribute__((always_inline)) {
     if (TQ) {
