@@ -435,6 +435,12 @@ def main():
         roof = None
         if args.profile_steps > 0:
             roof = profile_roofline(eng, args.profile_steps, args.precision, R, flops_step, value / world, args.profile_dump)
+            if roof and roof["kernel"].startswith("critic."):
+                # one weight-stationary workgroup owns a CU; with several engines per GPU a launch stays on 2 * runs workgroups (one round,
+                # ORL_WS_ONE_ROUND) and the other engines' kernels run on the CUs it leaves idle: `frac` is against the whole chip
+                cus = min(256, 2 * R) if os.environ.get("ORL_WS_ONE_ROUND") == "1" else 256
+                roof["cus_occupied_by_the_launch"] = cus
+                roof["frac_of_occupied_cus"] = roof["frac"] * 256.0 / cus
         for g in engines:
             g.close()
         engines = []
