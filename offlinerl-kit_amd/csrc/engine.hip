@@ -1014,7 +1014,7 @@ struct orl_buffer {
 extern "C" {
 
 const char* orl_last_error(void) { return g_err.c_str(); }
-const char* orl_version(void) { return "orl-engine 0.3 (gfx950; fp32 MFMA + split-bf16 MFMA; CQL IQL TD3BC EDAC)"; }
+const char* orl_version(void) { return "orl-engine 0.4 (gfx950; fp32 MFMA + split-bf16 MFMA; CQL IQL TD3BC EDAC SAC(MOPO) COMBO MCQ)"; }
 
 void orl_config_default(orl_config* c, int32_t algo) {
   memset(c, 0, sizeof(*c));
