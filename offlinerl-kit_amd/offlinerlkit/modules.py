@@ -73,6 +73,12 @@ class DiagGaussian(nn.Module):
         self._sigma_min = sigma_min
         self._sigma_max = sigma_max
 
+    def reset_parameters(self) -> None:
+        """the constructor's value of the module's OWN parameter (the Linear children reset themselves): sigma_param = 0"""
+        if not self._c_sigma:
+            with torch.no_grad():
+                self.sigma_param.zero_()
+
     def _params(self, logits):
         mu = self.mu(logits)
         if not self._unbounded:

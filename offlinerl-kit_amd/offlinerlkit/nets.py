@@ -50,12 +50,21 @@ class EnsembleLinear(nn.Module):
         super().__init__()
         self.num_ensemble = num_ensemble
         self.weight_decay = weight_decay
-        w = torch.zeros(num_ensemble, input_dim, output_dim)
-        nn.init.trunc_normal_(w, std=1.0 / (2.0 * input_dim ** 0.5))
-        self.weight = nn.Parameter(w)
+        self.input_dim = input_dim
+        self.weight = nn.Parameter(torch.zeros(num_ensemble, input_dim, output_dim))
         self.bias = nn.Parameter(torch.zeros(num_ensemble, 1, output_dim))
-        self.saved_weight = nn.Parameter(self.weight.detach().clone())
-        self.saved_bias = nn.Parameter(self.bias.detach().clone())
+        self.saved_weight = nn.Parameter(torch.zeros(num_ensemble, input_dim, output_dim))
+        self.saved_bias = nn.Parameter(torch.zeros(num_ensemble, 1, output_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        """the constructor's initialisation again (ensemble_linear.py:21-26): trunc_normal(std = 1 / (2 sqrt(in))) weights, zero
+        biases, shadow copies equal to them -- what building the layer under another seed gives (runs r > 0 of a multi-run policy)"""
+        with torch.no_grad():
+            nn.init.trunc_normal_(self.weight, std=1.0 / (2.0 * self.input_dim ** 0.5))
+            self.bias.zero_()
+            self.saved_weight.copy_(self.weight)
+            self.saved_bias.copy_(self.bias)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if x.dim() == 2:

@@ -106,7 +106,12 @@ class EnginePolicy(BasePolicy):
     def _before_unbind(self) -> None:
         pass
 
-    # -- engine options (before the first learn(), or any time: the engine is rebuilt around the current state) --------
+    def _after_bind_new_runs(self, first: int, n_runs: int) -> None:
+        """runs [first, n_runs) were added to a policy whose earlier runs carried their state over: give them the scalars
+        ``_after_bind`` gives a fresh engine (subclasses with per-run scalars)"""
+        pass
+
+    # -- engine options (before the first learn(), or any time: the engine is rebuilt around the current state, optimizer state included) --------
     def set_engine_options(self, n_runs: Optional[int] = None, seed: Optional[int] = None, precision: Optional[int] = None,
                            run_init: Optional[Callable[[int], Dict[str, Dict[str, torch.Tensor]]]] = None) -> "EnginePolicy":
         """``n_runs``: independent runs (seeds) this policy object trains together -- every kernel launch updates all of them
@@ -117,17 +122,19 @@ class EnginePolicy(BasePolicy):
         ``seed``: key of the device sampler / noise streams (default: derived from ``torch.initial_seed()`` and a per-process
         bind counter, so launcher seeds give independent streams and a re-bind never replays one).
         ``precision``: 0 exact fp32 MFMA (default), 1 split-bf16 MFMA (same 1e-4 parity gate on losses and Q-values, ~3x faster at many runs)."""
+        if n_runs is not None and n_runs < 1:
+            raise ValueError("n_runs must be >= 1")
+        if precision is not None and precision not in (0, 1):
+            raise ValueError("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)")
         if self._eng is not None:
-            self._unbind()
+            # an engine exists: the next bind restores parameters, Adam moments, step count and scalars of every run that survives
+            # (all of them when n_runs is unchanged; the first n_runs when it shrinks; new runs r >= old n_runs start fresh)
+            self._carried = self._unbind()
         if n_runs is not None:
-            if n_runs < 1:
-                raise ValueError("n_runs must be >= 1")
             self._n_runs = int(n_runs)
         if seed is not None:
             self._seed = int(seed)
         if precision is not None:
-            if precision not in (0, 1):
-                raise ValueError("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)")
             self._precision = int(precision)
         if run_init is not None:
             self._run_init = run_init
@@ -168,7 +175,9 @@ class EnginePolicy(BasePolicy):
         base = self._seed if self._seed is not None else torch.initial_seed()
         rng_state = torch.get_rng_state()
         try:
-            torch.manual_seed((int(base) + run) & 0x7FFFFFFFFFFFFFFF)
+            # the init stream of run r is keyed by mix(seed, r), not seed + r: a launcher that starts seeds s, s + 1, ... with several
+            # runs each (BASELINE configs[4]) must not hand run 1 of seed s the networks of run 0 of seed s + 1
+            torch.manual_seed(_mix64((int(base) & 0xFFFFFFFFFFFFFFFF) ^ _mix64(0x52554E00 + run)) & 0x7FFFFFFFFFFFFFFF)
             out = {}
             trainable = [nid for nid in nets if nid in (_engine.NET_ACTOR, _engine.NET_CRITIC1, _engine.NET_CRITIC2, _engine.NET_CRITIC_V,
                                                         _engine.NET_VAE_ENC, _engine.NET_VAE_DEC)]
@@ -177,6 +186,10 @@ class EnginePolicy(BasePolicy):
                 for sub in m.modules():
                     if hasattr(sub, "reset_parameters"):
                         sub.reset_parameters()
+                    elif next(sub.parameters(recurse=False), None) is not None:
+                        raise NotImplementedError(
+                            f"{type(sub).__name__} owns parameters but has no reset_parameters(): the default initialisation of runs r > 0 "
+                            "would silently start them from run 0's values -- pass run_init to set_engine_options")
                 out[nid] = {k: v.detach().clone() for k, v in m.named_parameters()}
         finally:
             torch.set_rng_state(rng_state)
@@ -224,8 +237,9 @@ class EnginePolicy(BasePolicy):
             for m in mod.modules():
                 if hasattr(m, "device") and isinstance(getattr(m, "device"), torch.device):
                     m.device = dev
+        n_carried = len(carried["params"]) if carried is not None else 0
         for r in range(R):
-            if carried is not None:
+            if r < n_carried:
                 params = carried["params"][r]
             elif r == 0:
                 params = {nid: dict(mod.named_parameters()) for nid, mod in nets.items()}
@@ -245,8 +259,10 @@ class EnginePolicy(BasePolicy):
         self._lr_pushed = {}
         self._push_lrs()
         if carried is not None:
-            for r in range(R):
+            for r in range(min(R, n_carried)):
                 self._eng.load_optimizer_state(carried["opt"][r], r)
+            if R > n_carried:
+                self._after_bind_new_runs(n_carried, R)
         else:
             self._after_bind()
         self._attached = None
@@ -286,6 +302,46 @@ class EnginePolicy(BasePolicy):
 
     def _on_select_run(self, run: int) -> None:
         pass
+
+    # -- every run's actor in one forward (evaluation of a multi-run policy) ------------------------------------------
+    def _stacked_net(self, nid: int) -> Dict[str, torch.Tensor]:
+        """{tensor name: [n_runs, *shape] strided view of the arena} -- the runs of a net sit at a fixed stride, so no copy is made"""
+        R = self._n_runs
+        base = self._arena.data_ptr()
+        off0 = (self._eng.net_ptr(0, nid) - base) // 4
+        stride = (self._eng.net_ptr(1, nid) - self._eng.net_ptr(0, nid)) // 4 if R > 1 else 0
+        out = {}
+        for name, off, shape in self._eng.net_tensors(nid):
+            inner = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
+            out[name] = self._arena.as_strided((R,) + tuple(shape), (stride,) + tuple(inner), off0 + off)
+        return out
+
+    def _eval_obs(self, obs: np.ndarray) -> np.ndarray:
+        """what ``select_action`` does to observations before the actor sees them (TD3BC: the scaler)"""
+        return obs
+
+    def _mode_from_hidden(self, h: torch.Tensor, P: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """deterministic action [n_runs, E, act_dim] from the backbone output [n_runs, E, H] and the stacked actor tensors"""
+        raise NotImplementedError
+
+    def select_action_runs(self, obs: np.ndarray) -> np.ndarray:
+        """Deterministic actions of EVERY run in one batched forward: ``obs`` [n_runs, E, obs_dim] -> [n_runs, E, act_dim]; row
+        (r, e) is what ``select_run(r); select_action(obs[r, e:e+1], deterministic=True)`` returns (mf_policy_trainer.py:100)."""
+        if self._eng is None:
+            raise RuntimeError("select_action_runs before the first learn(): no engine is bound yet")
+        obs = np.asarray(obs, dtype=np.float32)
+        if obs.ndim != 3 or obs.shape[0] != self._n_runs:
+            raise ValueError(f"obs: expected [n_runs = {self._n_runs}, E, obs_dim], got {obs.shape}")
+        R, E = obs.shape[:2]
+        x = np.asarray(self._eval_obs(obs.reshape(R * E, -1)), dtype=np.float32).reshape(R, E, -1)
+        P = self._stacked_net(_engine.NET_ACTOR)
+        with torch.no_grad():
+            h = torch.as_tensor(x, device=self._arena.device)
+            i = 0
+            while f"backbone.model.{2 * i}.weight" in P:
+                h = torch.relu(torch.baddbmm(P[f"backbone.model.{2 * i}.bias"].unsqueeze(1), h, P[f"backbone.model.{2 * i}.weight"].transpose(1, 2)))
+                i += 1
+            return self._mode_from_hidden(h, P).cpu().numpy()
 
     def _unbind(self):
         """Detach module parameters from the arena (clone) and drop the engine; returns what a re-bind carries over."""
@@ -335,28 +391,38 @@ class EnginePolicy(BasePolicy):
         reference's ``.item()`` calls; noise is drawn on the device (Philox) unless ``noise`` supplies the arrays of
         include/orl_engine.h's orl_noise in the reference's draw order (teacher-forced parity runs).  With ``n_runs`` > 1 the
         arrays either carry a leading run dimension or are shared by all runs."""
-        obs = batch["observations"]
         R = self._n_runs
-        per_run = R > 1 and obs.dim() == 3 if torch.is_tensor(obs) else (R > 1 and np.ndim(obs) == 3)
-        B = int(obs.shape[1] if per_run else obs.shape[0])
+        obs = batch["observations"]
+        if np.ndim(obs) not in (2, 3):
+            raise ValueError(f"observations: expected [B, obs_dim] or [n_runs, B, obs_dim], got shape {tuple(obs.shape)}")
+        B = int(obs.shape[-2])
         self._bind(B)
         dev = self._arena.device
         keep = []
         ptrs = {}
 
-        def dev_array(x):
+        def dev_array(name, x):
+            """every array decides for itself whether it carries a run dimension: [rows, cols] is shared by all runs (expanded),
+            [n_runs, rows, cols] is per run; anything else is refused (the engine reads n_runs * rows * cols floats)"""
             t = torch.as_tensor(x, dtype=torch.float32, device=dev)
-            if R > 1 and not per_run:
+            if t.dim() == 1:
+                t = t.unsqueeze(-1)                      # rewards / terminals as [B]
+            if t.dim() == 2:
                 t = t.unsqueeze(0).expand(R, *t.shape)
+            elif t.dim() != 3 or t.shape[0] != R:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} is neither [rows, cols] nor [n_runs = {R}, rows, cols]")
             t = t.contiguous()
             keep.append(t)
-            return t.data_ptr()
+            return t
         for k in ("observations", "actions", "next_observations", "rewards", "terminals"):
-            ptrs[k] = dev_array(batch[k])
+            t = dev_array(k, batch[k])
+            if t.shape[1] != B:
+                raise ValueError(f"{k}: {t.shape[1]} rows, observations have {B}")
+            ptrs[k] = t.data_ptr()
         self._push_lrs()
         nz = None
         if noise is not None:
-            nz = [dev_array(a) for a in noise]
+            nz = [dev_array(f"noise[{i}]", a).data_ptr() for i, a in enumerate(noise)]
         torch.cuda.current_stream(dev).synchronize()
         return self._result(self._eng.step(ptrs, nz, on_device=True))
 

@@ -55,6 +55,10 @@ class IQLPolicy(EnginePolicy):
                     critic_v_lr=float(self.critic_v_optim.param_groups[0]["lr"]), expectile=self._expectile,
                     iql_temperature=self._temperature)
 
+    def _mode_from_hidden(self, h, P):
+        mu = torch.tanh(torch.baddbmm(P["dist_net.mu.bias"].unsqueeze(1), h, P["dist_net.mu.weight"].transpose(1, 2)))    # max_mu = 1 (checked in _config)
+        return mu.clamp(float(self.action_space.low[0]), float(self.action_space.high[0]))
+
     def select_action(self, obs: np.ndarray, deterministic: bool = False) -> np.ndarray:
         if len(obs.shape) == 1:
             obs = obs.reshape(1, -1)

@@ -21,12 +21,16 @@ from .sac_family import CQLPolicy, _TanhGaussPolicy
 
 
 def _cat(batch: Dict) -> Dict:
+    """real rows first, then model rows (mopo.py:81-84 / combo.py:111-113); with a leading run dimension ([R, B, cols] arrays of a
+    multi-run policy) the ROW axis is the second to last one"""
     real, fake = batch["real"], batch["fake"]
     out = {}
     for k in real:
         a, b = real[k], fake[k]
-        out[k] = torch.cat([torch.as_tensor(a), torch.as_tensor(b).to(torch.as_tensor(a).device)], 0) if torch.is_tensor(a) or torch.is_tensor(b) \
-            else np.concatenate([np.asarray(a), np.asarray(b)], 0)
+        if np.ndim(a) != np.ndim(b) or np.ndim(a) < 2:
+            raise ValueError(f"{k}: real batch has shape {tuple(np.shape(a))}, model batch {tuple(np.shape(b))}: both must be [B, cols] or [R, B, cols]")
+        out[k] = torch.cat([torch.as_tensor(a), torch.as_tensor(b).to(torch.as_tensor(a).device)], -2) if torch.is_tensor(a) or torch.is_tensor(b) \
+            else np.concatenate([np.asarray(a), np.asarray(b)], -2)
     return out
 
 
@@ -144,7 +148,7 @@ class COMBOPolicy(CQLPolicy):
     def learn(self, batch: Dict, noise=None) -> Dict[str, float]:
         if "real" not in batch:
             raise ValueError("COMBOPolicy.learn expects {'real': batch, 'fake': batch} (combo.py:110-113)")
-        rows = (int(batch["real"]["observations"].shape[0]), int(batch["fake"]["observations"].shape[0]))
+        rows = (int(batch["real"]["observations"].shape[-2]), int(batch["fake"]["observations"].shape[-2]))
         if rows != self._rows:
             if self._eng is not None:      # the real / model split is part of the engine's row layout: rebuild around the current state
                 carried = self._unbind()

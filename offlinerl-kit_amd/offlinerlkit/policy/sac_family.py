@@ -37,9 +37,15 @@ class _TanhGaussPolicy(EnginePolicy):
         return dict(auto_alpha=0, alpha=self._fixed_alpha)
 
     def _after_bind(self) -> None:
+        if self._is_auto_alpha:      # every run starts from the caller's log_alpha (run_cql.py:102: zeros)
+            self._log_alpha_init = float(self._log_alpha.detach().cpu().reshape(-1)[0])
+        self._after_bind_new_runs(0, self._n_runs)
+
+    def _after_bind_new_runs(self, first: int, n_runs: int) -> None:
         if self._is_auto_alpha:
-            for r in range(self._n_runs):       # every run starts from the caller's log_alpha (run_cql.py:102: zeros)
-                self._eng.set_scalar(r, _engine.SCALAR_LOG_ALPHA, float(self._log_alpha.detach().cpu().reshape(-1)[0]))
+            v = getattr(self, "_log_alpha_init", float(self._log_alpha.detach().cpu().reshape(-1)[0]))
+            for r in range(first, n_runs):
+                self._eng.set_scalar(r, _engine.SCALAR_LOG_ALPHA, v)
 
     def _before_unbind(self) -> None:
         self.sync_scalars()
@@ -71,6 +77,9 @@ class _TanhGaussPolicy(EnginePolicy):
         with torch.no_grad():
             action, _ = self.actforward(obs, deterministic)
         return action.cpu().numpy()
+
+    def _mode_from_hidden(self, h, P):
+        return torch.tanh(torch.baddbmm(P["dist_net.mu.bias"].unsqueeze(1), h, P["dist_net.mu.weight"].transpose(1, 2)))   # TanhNormalWrapper.mode
 
     def _optims(self):
         o = {_engine.OPT_ACTOR: self.actor_optim}
@@ -137,9 +146,14 @@ class CQLPolicy(_TanhGaussPolicy):
         return c
 
     def _after_bind(self) -> None:
+        self._cql_log_alpha_init = float(self.cql_log_alpha.reshape(-1)[0])
         super()._after_bind()
-        for r in range(self._n_runs):
-            self._eng.set_scalar(r, _engine.SCALAR_CQL_LOG_ALPHA, float(self.cql_log_alpha.reshape(-1)[0]))
+
+    def _after_bind_new_runs(self, first: int, n_runs: int) -> None:
+        super()._after_bind_new_runs(first, n_runs)
+        v = getattr(self, "_cql_log_alpha_init", float(self.cql_log_alpha.reshape(-1)[0]))
+        for r in range(first, n_runs):
+            self._eng.set_scalar(r, _engine.SCALAR_CQL_LOG_ALPHA, v)
 
     def sync_scalars(self) -> None:
         super().sync_scalars()

@@ -61,6 +61,12 @@ class TD3BCPolicy(EnginePolicy):
                     policy_noise=self._policy_noise, noise_clip=self._noise_clip, td3bc_alpha=self._alpha,
                     max_action=float(self._max_action), update_actor_freq=int(self._freq))
 
+    def _eval_obs(self, obs):
+        return self.scaler.transform(obs) if self.scaler is not None else obs
+
+    def _mode_from_hidden(self, h, P):
+        return float(self._max_action) * torch.tanh(torch.baddbmm(P["last.bias"].unsqueeze(1), h, P["last.weight"].transpose(1, 2)))
+
     def select_action(self, obs: np.ndarray, deterministic: bool = False) -> np.ndarray:
         if self.scaler is not None:
             obs = self.scaler.transform(obs)

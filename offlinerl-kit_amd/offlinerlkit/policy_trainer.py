@@ -10,7 +10,9 @@ checkpoint) and the same return value.  Two inner loops:
 Evaluation: ``eval_env`` may be ONE env (the reference's sequential loop, verbatim) or a list of envs, which are stepped in
 lockstep with one batched ``select_action`` forward per step under the same episode accounting.
 Several runs per policy object (``policy.n_runs`` > 1, BASELINE config 5): the epoch's training is still one ``learn_n``; every
-run is evaluated, logged as ``run<i>/<key>`` (plain keys = mean over runs) and checkpointed as ``policy_run<i>.pth``.
+run is evaluated, logged as ``run<i>/<key>`` (plain keys = mean over runs) and checkpointed as ``policy_run<i>.pth``.  With
+``eval_env`` = one list of envs per run the runs are evaluated TOGETHER (one run-batched forward per env step,
+``policy.select_action_runs``); with a single env or a flat list they are evaluated one after another (``select_run``).
 Multi-GPU: independent runs, one process per GPU (replicas only).  When ``torch.distributed`` is initialised the
 per-epoch metric vector of every rank is all-gathered (RCCL over xGMI on GPUs, gloo on CPU) so rank 0 can log
 all runs; no other collective exists on this path.
@@ -96,10 +98,15 @@ class MFPolicyTrainer:
             if n_runs == 1:
                 eval_info = self._evaluate()
             else:
+                grouped = self._env_groups(n_runs)
+                per_run_all = self._evaluate_runs_batched(grouped) if grouped is not None else None
                 per_run = []
                 for r in range(n_runs):
-                    self.policy.select_run(r)
-                    per_run.append(self._evaluate())
+                    if per_run_all is not None:
+                        per_run.append(per_run_all[r])
+                    else:
+                        self.policy.select_run(r)
+                        per_run.append(self._evaluate())
                     self.logger.logkv(f"run{r}/eval/episode_reward", float(np.mean(per_run[-1]["eval/episode_reward"])))
                     self.logger.logkv(f"run{r}/eval/episode_length", float(np.mean(per_run[-1]["eval/episode_length"])))
                     if hasattr(self._score_env(), "get_normalized_score"):
@@ -138,7 +145,10 @@ class MFPolicyTrainer:
                 torch.save(self.policy.run_state_dict(r), os.path.join(where, f"policy_run{r}.pth"))
 
     def _score_env(self):
-        return self.eval_env[0] if isinstance(self.eval_env, (list, tuple)) else self.eval_env
+        e = self.eval_env
+        while isinstance(e, (list, tuple)):
+            e = e[0]
+        return e
 
     def _evaluate(self) -> Dict[str, List[float]]:
         if isinstance(self.eval_env, (list, tuple)):
@@ -158,6 +168,47 @@ class MFPolicyTrainer:
                 obs = self.eval_env.reset()
         return {"eval/episode_reward": [d["episode_reward"] for d in done_eps],
                 "eval/episode_length": [d["episode_length"] for d in done_eps]}
+
+    def _env_groups(self, n_runs: int):
+        """``eval_env`` given as one list of envs PER RUN ([[env, ...]] * n_runs) -> those groups, else None (sequential evaluation)"""
+        ev = self.eval_env
+        if isinstance(ev, (list, tuple)) and len(ev) == n_runs and all(isinstance(g, (list, tuple)) and len(g) > 0 for g in ev) \
+                and len({len(g) for g in ev}) == 1 and hasattr(self.policy, "select_action_runs"):
+            return [list(g) for g in ev]
+        return None
+
+    def _evaluate_runs_batched(self, groups) -> List[Dict[str, List[float]]]:
+        """All runs of a multi-run policy evaluated together: run r owns the envs ``groups[r]``; every step is ONE run-batched
+        deterministic forward over [n_runs, E, obs_dim] (``policy.select_action_runs``) instead of n_runs x E one-row forwards and
+        n_runs full rollouts one after another.  Per run the episode accounting is ``_evaluate_batched``'s."""
+        self.policy.eval()
+        R, E = len(groups), len(groups[0])
+        obs = [[np.asarray(env.reset(), dtype=np.float32).reshape(-1) for env in g] for g in groups]
+        started = [min(E, self._eval_episodes)] * R
+        active = [[i < started[r] for i in range(E)] for r in range(R)]
+        ep_reward = [[0.0] * E for _ in range(R)]
+        ep_len = [[0] * E for _ in range(R)]
+        done_eps: List[List[Dict[str, float]]] = [[] for _ in range(R)]
+        while any(len(d) < self._eval_episodes for d in done_eps):
+            actions = self.policy.select_action_runs(np.stack([np.stack(o) for o in obs]))
+            for r in range(R):
+                for i in range(E):
+                    if not active[r][i]:
+                        continue
+                    o, reward, terminal, _ = groups[r][i].step(np.asarray(actions[r, i]).flatten())
+                    obs[r][i] = np.asarray(o, dtype=np.float32).reshape(-1)
+                    ep_reward[r][i] += reward
+                    ep_len[r][i] += 1
+                    if terminal:
+                        done_eps[r].append({"episode_reward": ep_reward[r][i], "episode_length": ep_len[r][i]})
+                        ep_reward[r][i], ep_len[r][i] = 0.0, 0
+                        if started[r] < self._eval_episodes:
+                            started[r] += 1
+                            obs[r][i] = np.asarray(groups[r][i].reset(), dtype=np.float32).reshape(-1)
+                        else:
+                            active[r][i] = False
+        return [{"eval/episode_reward": [d["episode_reward"] for d in de], "eval/episode_length": [d["episode_length"] for d in de]}
+                for de in done_eps]
 
     def _evaluate_batched(self, envs) -> Dict[str, List[float]]:
         """E envs in lockstep: one [E, obs_dim] deterministic forward per step instead of E one-row forwards.  Episode accounting
