@@ -1,0 +1,192 @@
+"""GPU: the backward kernels against a float64 restatement ON THE ENGINE'S OWN operands -- critic input rows, dL/dq, the packed
+ReLU masks (and, for EDAC's gradient-diversity sweep, the engine's own gamma) -- for the paths tests/test_gpu_grads.py's check (1)
+did not cover: three hidden layers (CQL [256,256,256]: ``ws_dgrad<W0 = false, STORE = true>`` for the middle layer, tiled wgrads)
+and EDAC's ensemble critics (TD backward + the analytic double backward: ``edac.delta*``, ``k_edac_gamma``, ``edac.t*``,
+``edac.wgrad*``), in every precision the engine offers.
+
+Reference: what autograd leaves in ``param.grad`` (cql.py:180-190; edac.py:133-154 with ``create_graph=True``).
+
+Bar, for EVERY element of every gradient tensor:  |g_hip - g_f64| <= C(precision) * (the same sum with every term replaced by its
+absolute value, forward bounds included) -- the componentwise backward-error bound of arithmetic whose operands carry p significand
+bits and whose sums are accumulated in fp32:
+    precision 0 (exact fp32 MFMA): C = 16 * 2^-24 (exact operands; what is bounded is the fp32 accumulation over up to 7936 rows and the
+    forward's rounding carried by the backward operands -- measured 0.40 / 0.46 of it)      precision 1 (split operands, hi + lo): C = 4 * 2^-17
+    (measured 0.05 / 0.19 of it)
+A structural error (a dropped row group, a wrong operand pairing, a mis-indexed member) exceeds the bound by orders of magnitude;
+rounding cannot.  This replaces comparing a gradient with the fp32 numpy oracle at a widened bar: the oracle's own fp32 sums and
+its own ReLU decisions on pre-activations within an ulp of zero are not part of the statement here, because the float64 side is
+given the masks the engine packed (they are compared with the float64 masks separately: the few that differ must sit on
+pre-activations within rounding distance of zero)."""
+import numpy as np
+import pytest
+
+import synth
+import test_gpu_algos as ta
+import test_gpu_cql as tc
+from helpers import clone_state
+from test_gpu_grads import _unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+BOUND = {0: 16.0 * 2.0 ** -24, 1: 4.0 * 2.0 ** -17}
+
+
+def mlp_backward_f64(x, dq, Ws, bs, w_tail, masks):
+    """float64 forward / backward of an MLP with a single-output tail on given input rows, dL/dq and ReLU masks.
+    Ws[l]: [out, in] (nn.Linear layout), masks[l]: [rows, out] bool.  Returns per-layer (dW, db) lists + the tail's, the
+    absolute-value sums of the same expressions, the pre-activations, and the unit-seed deltas (dq = 1)."""
+    f = np.float64
+    L = len(Ws)
+    Ws = [w.astype(f) for w in Ws]
+    bs = [b.astype(f).ravel() for b in bs]
+    wt = w_tail.astype(f).ravel()
+    x, dq = x.astype(f), dq.astype(f).ravel()
+    hs, ahs, zs = [x], [np.abs(x)], []
+    for l in range(L):
+        z = hs[-1] @ Ws[l].T + bs[l]
+        zs.append(z)
+        hs.append(z * masks[l])
+        ahs.append((ahs[-1] @ np.abs(Ws[l]).T + np.abs(bs[l])) * masks[l])      # forward bounds: the backward operands carry the forward's rounding
+    delta = [None] * L                                                           # unit-seed backward dq_k/dz_l
+    adelta = [None] * L
+    delta[L - 1] = wt[None, :] * masks[L - 1]
+    adelta[L - 1] = np.abs(wt)[None, :] * masks[L - 1]
+    for l in range(L - 1, 0, -1):
+        delta[l - 1] = (delta[l] @ Ws[l]) * masks[l - 1]
+        adelta[l - 1] = (adelta[l] @ np.abs(Ws[l])) * masks[l - 1]
+    g = {"tail_w": (dq[:, None] * hs[L]).sum(0), "tail_b": np.array([dq.sum()])}
+    a = {"tail_w": (np.abs(dq)[:, None] * ahs[L]).sum(0), "tail_b": np.array([np.abs(dq).sum()])}
+    for l in range(L):
+        dz, adz = dq[:, None] * delta[l], np.abs(dq)[:, None] * adelta[l]
+        g[f"W{l}"], g[f"b{l}"] = dz.T @ hs[l], dz.sum(0)
+        a[f"W{l}"], a[f"b{l}"] = adz.T @ ahs[l], adz.sum(0)
+    return g, a, zs, (delta, adelta, hs, ahs)
+
+
+def check_masks(zs, masks, tag):
+    flips = 0
+    for l, (z, m) in enumerate(zip(zs, masks)):
+        flip = m != (z > 0)
+        flips += int(flip.sum())
+        assert flip.mean() < 2e-4, (tag, l, "mask flips", flip.mean())
+        if flip.any():
+            assert np.abs(z[flip]).max() < 2e-4 * np.sqrt((z * z).mean()), (tag, l, np.abs(z[flip]).max())
+    return flips
+
+
+def worst_ratio(got, g, a, C, tag):
+    err = np.abs(np.asarray(got, np.float64).reshape(g.shape) - g)
+    ratio = float((err / (C * a + 1e-30)).max())
+    assert ratio < 1.0, (tag, "componentwise backward error / bound", ratio)
+    return ratio
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_cql_three_layer_critic_backward_is_componentwise_backward_stable(precision):
+    """CQL [256,256,256] (run_cql.py:31) at 32 runs: fused first + second layer forward, storing weight-stationary dgrad for the
+    middle layer, tiled wgrads, weight-stationary top-layer dgrad -- every critic gradient tensor of the first and the last run."""
+    R = 32
+    eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=precision)
+    c = synth.CQL_CASES["cql_halfcheetah_h3"]
+    B, N, od, ad, L = c["B"], c["N"], c["obs_dim"], c["act_dim"], len(c["hidden"])
+    Mc = B + 3 * B * N
+    try:
+        pre = clone_state({k: st[k] for k in ("critic1", "critic2")})
+        eng.step(tc.lead(batches[0], R), tc.lead(tc.noise_list(noises[0]), R))
+        worst, flips = 0.0, 0
+        for r in (0, R - 1):
+            xc = eng.debug_read(r, "xc").reshape(Mc, -1)[:, :od + ad]
+            masks = [_unpack_bits(eng.debug_read_bits(r, f"ch{l}"), 2, Mc, c["hidden"][l]) for l in range(L)]
+            for ci, nm in enumerate(("critic1", "critic2")):
+                net = pre[nm]
+                dq = eng.debug_read(r, f"dq{ci + 1}")
+                Ws = [net[f"backbone.model.{2 * l}.weight"] for l in range(L)]
+                bs = [net[f"backbone.model.{2 * l}.bias"] for l in range(L)]
+                g, a, zs, _ = mlp_backward_f64(xc, dq, Ws, bs, net["last.weight"], [m[ci] for m in masks])
+                flips += check_masks(zs, [m[ci] for m in masks], (precision, r, nm))
+                got = eng.debug_grads(r, tc.NETS[nm])
+                names = {"last.weight": "tail_w", "last.bias": "tail_b"}
+                for l in range(L):
+                    names[f"backbone.model.{2 * l}.weight"], names[f"backbone.model.{2 * l}.bias"] = f"W{l}", f"b{l}"
+                for pn, key in names.items():
+                    worst = max(worst, worst_ratio(got[pn], g[key], a[key], BOUND[precision], (precision, r, nm, pn)))
+        print(f"CQL h3 critic backward, precision {precision}: worst |err| / (C * abs-sum) = {worst:.3f}; mask flips vs float64: {flips}")
+    finally:
+        eng.close()
+
+
+def edac_gamma_f64(g, eta, K, B):
+    """d(eta * L_g)/dg of edac.py:141-149 in float64: g [K, B, A] -> gamma [K, B, A], and the loss term itself"""
+    g = g.astype(np.float64)
+    nrm = np.sqrt((g * g).sum(axis=2, keepdims=True))
+    nk = nrm + 1e-10
+    gh = g / nk
+    S = gh.sum(axis=0, keepdims=True)
+    gram_off = (S * S).sum(axis=2)[0] - (gh * gh).sum(axis=2).sum(axis=0)
+    grad_loss = gram_off.mean() / (K - 1)
+    c = (eta * 2.0 / ((K - 1) * B)) * (S - gh)
+    safe = np.where(nrm > 0, nrm, 1.0)
+    return c / nk - g * ((g * c).sum(axis=2, keepdims=True) / (nk * nk * safe)), grad_loss
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_edac_critic_backward_and_diversity_sweep_are_componentwise_backward_stable(precision):
+    """EDAC, walker2d shapes (K = 10, [256,256,256], eta = 5) at 128 runs: on the engine's own (obs | act) rows, dL_TD/dq and packed
+    masks, float64 gives (i) the action gradients g = dQ_k/da of the unit-seed backward (``edac.delta*``), (ii) gamma from the
+    ENGINE's g (``k_edac_gamma``: plain fp32 arithmetic, compared at fp32 rounding), (iii) the total critic gradients = TD backward +
+    the masked forward sweep seeded with the ENGINE's gamma (``edac.t*``, ``edac.wgrad*``).  Every element inside the bound."""
+    R = 128
+    case = ta._full_size_case("edac")
+    eng, mod, cfg, st, batches, noises = ta.make_engine("edac", case, n_runs=R, precision=precision)
+    c = synth.EDAC_CASES[case]
+    B, od, ad, hid, K = c["B"], c["obs_dim"], c["act_dim"], c["hidden"], cfg["num_critics"]
+    L = len(hid)
+    C = BOUND[precision]
+    try:
+        pre = ta._strip_saved({k: np.array(v, copy=True) for k, v in st["critics"].items()})
+        b, n = batches[0], noises[0]
+        nl = ta.noise_list("edac", n)
+        eng.step({kk: np.stack([v] * R) for kk, v in b.items()}, [np.stack([v] * R) for v in nl])
+        worst = {"g": 0.0, "grads": 0.0}
+        flips = 0
+        for r in (0, R - 1):
+            xq = eng.debug_read(r, "xq").reshape(B, -1)[:, :od + ad]
+            dqs = eng.debug_read(r, "dqs").reshape(K, B)
+            g_eng = eng.debug_read(r, "g").reshape(K, B, ad)
+            gam_eng = eng.debug_read(r, "gamma").reshape(K, B, ad)
+            masks = [_unpack_bits(eng.debug_read_bits(r, f"ch{l}"), K, B, hid[l]) for l in range(L)]
+            got = eng.debug_grads(r, ta.NET_IDS["edac"]["critics"])
+            gam64, _ = edac_gamma_f64(g_eng, cfg["eta"], K, B)
+            gscale = np.abs(gam64).max()
+            assert np.abs(gam_eng - gam64).max() < 2e-5 * gscale, ("gamma", r, np.abs(gam_eng - gam64).max() / gscale)
+            for k in range(K):
+                Ws = [pre[f"model.{2 * l}.weight"][k].T for l in range(L)]                 # EnsembleLinear (in, out) -> [out, in]
+                bs = [pre[f"model.{2 * l}.bias"][k] for l in range(L)]
+                wt = pre[f"model.{2 * L}.weight"][k]
+                mk = [m[k] for m in masks]
+                g, a, zs, (delta, adelta, hs, ahs) = mlp_backward_f64(xq, dqs[k], Ws, bs, wt, mk)
+                flips += check_masks(zs, mk, (precision, r, k))
+                # (i) action gradients of the unit-seed backward
+                W0a = Ws[0][:, od:].astype(np.float64)                                      # [H, A]
+                g64, ag = delta[0] @ W0a, adelta[0] @ np.abs(W0a)
+                worst["g"] = max(worst["g"], worst_ratio(g_eng[k], g64, ag, C, (precision, r, k, "g")))
+                # (iii) diversity sweep seeded with the engine's gamma, added to the TD gradients
+                gam = gam_eng[k].astype(np.float64)
+                t, at = (gam @ W0a.T) * mk[0], (np.abs(gam) @ np.abs(W0a).T) * mk[0]
+                g["W0"][:, od:] += delta[0].T @ gam
+                a["W0"][:, od:] += adelta[0].T @ np.abs(gam)
+                for l in range(1, L):
+                    g[f"W{l}"] += delta[l].T @ t
+                    a[f"W{l}"] += adelta[l].T @ at
+                    t, at = (t @ Ws[l].astype(np.float64).T) * mk[l], (at @ np.abs(Ws[l]).astype(np.float64).T) * mk[l]
+                g["tail_w"] = g["tail_w"] + t.sum(0)
+                a["tail_w"] = a["tail_w"] + at.sum(0)
+                for l in range(L + 1):
+                    wkey, bkey = (f"W{l}", f"b{l}") if l < L else ("tail_w", "tail_b")
+                    gw = got[f"model.{2 * l}.weight"][k]                                    # (in, out)
+                    ref_w, ref_a = (g[wkey].T, a[wkey].T) if l < L else (g[wkey][:, None], a[wkey][:, None])
+                    worst["grads"] = max(worst["grads"], worst_ratio(gw, ref_w, ref_a, C, (precision, r, k, f"model.{2 * l}.weight")))
+                    worst["grads"] = max(worst["grads"], worst_ratio(got[f"model.{2 * l}.bias"][k].ravel(), g[bkey], a[bkey], C, (precision, r, k, f"model.{2 * l}.bias")))
+        print(f"EDAC critic backward + diversity sweep, precision {precision}: worst ratio g {worst['g']:.3f}, gradients {worst['grads']:.3f}; mask flips vs float64: {flips}")
+    finally:
+        eng.close()
