@@ -21,7 +21,12 @@
  *     host-side arrays have a leading run dimension [n_runs][...].
  *   - all floating point is fp32.  `precision` selects the MFMA scheme used by
  *     the GEMMs only: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32),
- *     1 = split-bf16 (3 bf16 MFMAs per product, fp32 accumulate).
+ *     1 = split operands: every operand as hi + lo 16-bit planes (IEEE half:
+ *     22 significand bits per operand, power-of-two operand scales folded back
+ *     into the fp32 accumulators), 3 MFMAs per product, fp32 accumulate;
+ *     orl_split_bits() reports the operand width of the loaded build (22; 16
+ *     for the bf16-plane variant build).  In this mode hidden activations
+ *     and inputs must stay below 65504 in magnitude (fp16 range).
  */
 #ifndef ORL_ENGINE_H
 #define ORL_ENGINE_H
@@ -114,6 +119,13 @@ typedef struct orl_config {
    * actions is num_repeat_actions, the VAE's max_action is max_action */
   int32_t vae_hidden, vae_latent;
   float mcq_lambda, behavior_lr;
+  /* launch geometry of the weight-stationary kernels (csrc/ws_gemm.h), per engine:
+   *   ws_one_round  0 (default): as many workgroups per net as fill whole rounds of the CUs; 1: CUs / nets workgroups per net, one round
+   *                 (what a process that runs SEVERAL engines per GPU wants: the CUs one engine's launch leaves idle are where the
+   *                 other engines' kernels run; bench.py's two-engine default);
+   *   ws_cus        CUs one launch spreads over, 8..256 (0 = 256).
+   * The environment variables ORL_WS_ONE_ROUND / ORL_WS_CUS, when set, override these fields; they are read once, in orl_engine_create. */
+  int32_t ws_one_round, ws_cus;
   /* optional caller-owned parameter arena (device pointer, orl_arena_floats()
    * floats) so that framework tensors can alias engine parameters; NULL = the
    * engine allocates with hipMalloc. */
@@ -148,6 +160,7 @@ typedef struct orl_engine orl_engine;
 /* -- lifecycle --------------------------------------------------------------- */
 const char* orl_last_error(void);
 const char* orl_version(void);
+int orl_split_bits(void); /* significand bits an operand carries at precision 1 (22: fp16 hi + lo planes; 16: the bf16-plane variant build) */
 void orl_config_default(orl_config* cfg, int32_t algo); /* script defaults: run_{cql,iql,td3bc,edac}.py get_args() */
 int64_t orl_arena_floats(const orl_config* cfg);        /* size of the parameter arena for external_arena */
 int orl_engine_create(const orl_config* cfg, orl_engine** out); /* replaces <Algo>Policy.__init__ + deepcopy of targets (sac.py:29-33) */

@@ -153,7 +153,15 @@ struct Engine {
   long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
   bool use_ws32 = true;        // ... and their exact-fp32 variants at precision 0 (ORL_WS32=0: tiled fp32 kernels only)
+  WsGeom ws_geo;               // workgroups per net / CUs per launch of the weight-stationary kernels (orl_config::ws_one_round, ws_cus)
   bool ws_precision_ok() const { return use_ws && (cfg.precision == 1 || (cfg.precision == 0 && use_ws32)); }
+  // split precision: per-run dynamic power-of-two scale of the gradient matrices of the backward pass being enqueued (k_grad_scale);
+  // one slot per backward pass of a step, fixed order, so a captured graph replays with the same slots
+  float* gscale_buf = nullptr;       // [GSCALE_SLOTS][R]
+  enum { GSCALE_SLOTS = 24 };
+  int gscale_next = 0;
+  const float* cur_gscale = nullptr; // scale array [R] of the current backward pass (null: precision 0 or outside a backward pass)
+  const float* grad_scale(const Mat& seed, int rows, int cols, int nets, const char* tag);
 
   ~Engine();
   int init(const orl_config& c);
@@ -167,12 +175,13 @@ struct Engine {
   // launch helpers (enqueue on stream)
   int linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH, const char* tag,
                  int in_row0 = 0, int in_rows = -1, const Mat* tail_out = nullptr, bool* tail_fused = nullptr,
-                 const Mat* fuse_X0 = nullptr, const char* tag0 = nullptr);
+                 const Mat* fuse_X0 = nullptr, const char* tag0 = nullptr, const float* x_dscale = nullptr);
   int tq_scratch_nets = 2;
   int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag,
                    const Mat* w0_X = nullptr, bool store_dx = true, int* w0_slabs = nullptr);
   int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                   const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr, int* slabs_out = nullptr);
+                   const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr, int* slabs_out = nullptr,
+                   const float* x_dscale = nullptr);
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
   int polyak(int target_net, int src_net, int nnets);
   void prof_begin(const char* name, double flops, double bytes = 0);

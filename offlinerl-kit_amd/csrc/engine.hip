@@ -277,6 +277,19 @@ void Engine::prof_end() {
   hipEventRecord(prof.back().b, stream);
 }
 
+// split precision: choose the dynamic scale of a backward pass from its seed (kernels.h: k_grad_scale); null at precision 0
+const float* Engine::grad_scale(const Mat& seed, int rows, int cols, int nets, const char* tag) {
+  if (cfg.precision != 1) return nullptr;
+  if (gscale_next >= GSCALE_SLOTS) { fail("grad_scale: out of slots"); return nullptr; }
+  float* out = gscale_buf + (long)(gscale_next++) * R;
+  GradScaleP g;
+  g.seed = seed.p; g.rs = seed.rs; g.cs = seed.cs; g.rows = rows; g.cols = cols; g.pitch = seed.pitch; g.nets = nets; g.out = out;
+  prof_begin((std::string(tag) + ".gscale").c_str(), 0);
+  hipLaunchKernelGGL(k_grad_scale, dim3(R), dim3(256), 0, stream, g);
+  prof_end();
+  return out;
+}
+
 #define ORL_LAUNCH(tag, kernel, grid, block, ...)                                      \
   do {                                                                                 \
     prof_begin(tag, 0);                                                                \
@@ -312,12 +325,14 @@ struct DY {
 // fuse_X0 (layer == 1 only): X = hs[0] has not been computed yet; it is relu(fuse_X0 W0^T + b0).  The weight-stationary kernel
 // produces it inside this launch (stores it to X for the backward pass); any other path first runs layer 0 on its own.
 int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const Mat& Y, int epi, const Mat* maskH,
-                       const char* tag, int in_row0, int in_rows, const Mat* tail_out, bool* tail_fused, const Mat* fuse_X0, const char* tag0) {
+                       const char* tag, int in_row0, int in_rows, const Mat* tail_out, bool* tail_fused, const Mat* fuse_X0, const char* tag0,
+                       const float* x_dscale) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
   GemmP p;
   memset(&p, 0, sizeof(p));
+  p.b_scale = ORL_WSCALE; p.a_dscale = x_dscale;      // split precision: static scale of the weight operand, dynamic one of a gradient-like input
   p.A = {X.p, X.rs, X.cs};
   p.a_sr = X.pitch; p.a_sk = 1;
   if (l.ens) { p.B = {nr.base + l.w_off[layer] + (long)in_row0 * out, nr.rs, l.w_ms[layer]}; p.b_sr = 1; p.b_sk = out; p.b_rlim = out & ~3; }
@@ -374,7 +389,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       prof_begin(tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
                  4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (double)M * in + (double)out * in + (elide ? (double)M * out / 32 : (double)M * out)));
       if (fused0) bits_live.insert(X.bits);
-      hipError_t err = launch_ws_fwd(w, nz, stream);
+      hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
       bits_live.insert(Y.bits);
@@ -433,6 +448,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   GemmP p;
   memset(&p, 0, sizeof(p));
+  p.a_dscale = cur_gscale; p.b_scale = ORL_WSCALE;     // split precision: A = a gradient matrix of the current backward pass, B = weights
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
   p.a_sr = dy.m.pitch; p.a_sk = 1;
   if (dy.rank1) {
@@ -466,9 +482,9 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
     w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab);
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
       prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
                  nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (w0_X->pitch + 1) + 4.0 * per_z * in * (l.layer_in(0) + 1)));
       hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
@@ -492,7 +508,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
     if (ws_dgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, 1 << 20);
+      const int per_z = ws_dgrad_blocks(M, nz, 1 << 20, ws_geo);
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
       hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
       prof_end();
@@ -524,10 +540,10 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.Y = dX.p; w.y_s0 = dX.rs; w.y_s1 = dX.cs; w.y_pitch = dX.pitch;
     w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_fwd_supported(w, out, in)) {
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
-      hipError_t err = launch_ws_fwd(w, nz, stream);
+      hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws dgrad launch ") + tag + ": " + hipGetErrorString(err));
       return 0;
@@ -586,7 +602,7 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
 
 // slabs_out: number of split-K slabs actually written (== ksplit unless the weight-stationary kernel chose its own decomposition)
 int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                         const char* tag, int in_row0, int in_rows, bool* fuse_tail, int* slabs_out) {
+                         const char* tag, int in_row0, int in_rows, bool* fuse_tail, int* slabs_out, const float* x_dscale) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
@@ -594,6 +610,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   if (vals_dead.count(X.p)) return fail(std::string("wgrad ") + tag + ": the input activation was not stored by the forward pass");
   GemmP p;
   memset(&p, 0, sizeof(p));
+  p.a_dscale = cur_gscale; p.b_dscale = x_dscale;      // split precision: A = dY^T of the current backward pass; B = X (an activation, or a gradient-like matrix with its own scale)
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
   p.a_sr = 1; p.a_sk = dy.m.pitch;
   if (out == 1 && dy.m.pitch == 1 && !dy.rank1) p.a_sr = 4;   // a [1 x M] row vector: k-contiguous, any row stride -> vector loads
@@ -637,9 +654,9 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       w.b1 = nr.base + l.b_off[layer]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[layer];
     } else { w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch; }
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
       prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
                  nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
@@ -730,13 +747,17 @@ static std::vector<std::pair<long, int>> make_segs(const NetLayout& l, const std
 struct BwdOut { std::vector<int> ks; };
 static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::vector<Mat>& hs, int M, const Mat& dTail,
                         std::vector<Mat>& dz, bool want_w, bool want_dx, int dx_col0, int dx_ncols, const Mat* dX,
-                        const char* tag, BwdOut* out) {
+                        const char* tag, BwdOut* out, const float* gscale_given = nullptr) {
   const NetLayout& l = *nr.lay;
   const int L = l.L;
   const bool rank1 = (l.out_dim == 1);
   const int nz = e->R * nr.nz1;
   std::vector<int> ks(L + 1, 1);
   std::string t = tag;
+  // split precision: every gradient matrix of this pass enters the MFMAs times one dynamic power-of-two scale per run, chosen from the seed
+  struct ScaleScope { Engine* e; const float* prev; ~ScaleScope() { e->cur_gscale = prev; } } scope{e, e->cur_gscale};
+  e->cur_gscale = gscale_given ? gscale_given : e->grad_scale(dTail, M, l.out_dim, nr.nz1, tag);
+  if (e->cfg.precision == 1 && !e->cur_gscale) return -1;
   if (want_w) {
     for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->ksplit_cap);
     if (!rank1 && e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
@@ -857,7 +878,8 @@ int Engine::init(const orl_config& c) {
   scalars = (RunScalars*)raw_alloc(sizeof(RunScalars) * R);
   hyper = (Hyper*)raw_alloc(sizeof(Hyper));
   gstep = (unsigned long long*)raw_alloc(sizeof(unsigned long long));
-  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep) return fail("hipMalloc state");
+  gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
+  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf) return fail("hipMalloc state");
   memset(&hyper_host, 0, sizeof(hyper_host));
   hyper_host.lr[ORL_OPT_ACTOR] = c.actor_lr;
   hyper_host.lr[ORL_OPT_CRITIC] = c.critic_lr;
@@ -874,6 +896,11 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
   { const char* f = getenv("ORL_WS32"); use_ws32 = !(f && atoi(f) == 0); }
+  // launch geometry of the weight-stationary kernels: config fields, overridden once (here) by the environment
+  ws_geo.one_round = c.ws_one_round != 0;
+  ws_geo.cus = (c.ws_cus >= 8 && c.ws_cus <= 256) ? c.ws_cus : 256;
+  { const char* f = getenv("ORL_WS_ONE_ROUND"); if (f) ws_geo.one_round = atoi(f) != 0; }
+  { const char* f = getenv("ORL_WS_CUS"); const int x = f ? atoi(f) : 0; if (x >= 8 && x <= 256) ws_geo.cus = x; }
   if (build_common()) return -1;
   int rc = -1;
   switch (c.algo) {
@@ -984,6 +1011,7 @@ int Engine::step_variant() const {
 
 int Engine::enqueue_step(int variant) {
   int rc = -1;
+  gscale_next = 0; cur_gscale = nullptr;
   switch (cfg.algo) {
     case ORL_ALGO_CQL: rc = cql_step(); break;
     case ORL_ALGO_IQL: rc = iql_step(); break;
@@ -1014,7 +1042,12 @@ struct orl_buffer {
 extern "C" {
 
 const char* orl_last_error(void) { return g_err.c_str(); }
-const char* orl_version(void) { return "orl-engine 0.4 (gfx950; fp32 MFMA + split-bf16 MFMA; CQL IQL TD3BC EDAC SAC(MOPO) COMBO MCQ)"; }
+#ifdef ORL_SPLIT_BF16
+const char* orl_version(void) { return "orl-engine 0.5 (gfx950; fp32 MFMA + split-bf16 MFMA; CQL IQL TD3BC EDAC SAC(MOPO) COMBO MCQ)"; }
+#else
+const char* orl_version(void) { return "orl-engine 0.5 (gfx950; fp32 MFMA + split-fp16 MFMA; CQL IQL TD3BC EDAC SAC(MOPO) COMBO MCQ)"; }
+#endif
+int orl_split_bits(void) { return ORL_SPLIT_BITS; }
 
 void orl_config_default(orl_config* c, int32_t algo) {
   memset(c, 0, sizeof(*c));
@@ -1339,9 +1372,14 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
       ORL_HIP(hipGraphInstantiate(&e.graph_exec[v], e.graph[v], nullptr, nullptr, 0));
     }
   }
-  hipEvent_t t0, t1;
-  ORL_HIP(hipEventCreate(&t0));
-  ORL_HIP(hipEventCreate(&t1));
+  // (the two timing events are released on every exit path, early error returns included)
+  struct EventPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() { if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+  } ev;
+  ORL_HIP(hipEventCreate(&ev.a));
+  ORL_HIP(hipEventCreate(&ev.b));
+  const hipEvent_t t0 = ev.a, t1 = ev.b;
   if (e.prof_on) { e.prof.clear(); e.ev_used = 0; }
   ORL_HIP(hipEventRecord(t0, e.stream));
   for (int s = 0; s < n_steps; ++s) {
@@ -1358,7 +1396,6 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   ORL_HIP(hipStreamSynchronize(e.stream));
   float ms = 0.f;
   ORL_HIP(hipEventElapsedTime(&ms, t0, t1));
-  hipEventDestroy(t0); hipEventDestroy(t1);
   if (elapsed_ms) *elapsed_ms = ms;
   if (metrics_mean) {
     std::vector<float> m(e.R * e.nm);

@@ -37,21 +37,57 @@
 namespace orl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- 16-bit operand type of the split-precision multiply (P_SPLIT) ----
+// Default: IEEE half (fp16) hi + lo planes = 22 significand bits per operand on v_mfma_f32_16x16x32_f16 (same cycles as the bf16 form).
+// fp16 has only 5 exponent bits, so every operand class carries a power-of-two scale that is folded back into the fp32 accumulators
+// (weights: static; gradient matrices: one dynamic scale per run and backward pass, k_grad_scale) -- exact, and it keeps hi in the normal
+// range and lo = x - hi on the 2^-24 subnormal grid or better (gfx950's f16 MFMA multiplies subnormals exactly and v_cvt_pk_f16_f32
+// rounds onto that grid: tools/fp16_split_probe.hip, profiles/r03_fp16_split_probe.txt).  Measured on 256-deep dot products: fp16
+// hi + lo with scales 2 - 3e-7 of the result scale = an fp32 fmaf chain's own error; bf16 hi + lo 4 - 5e-6.
+// -DORL_SPLIT_BF16 (build.py --variant) keeps the round-2 bf16 planes (8 + 8 bits, no range limit) for A/B runs.
+#ifdef ORL_SPLIT_BF16
+typedef __bf16 hx_t;
+#define ORL_SPLIT_BITS 16
+#define ORL_HX_ONE_BITS 0x3F80u                      // 1.0 as a 16-bit pattern
+#define ORL_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#else
+typedef _Float16 hx_t;
+#define ORL_SPLIT_BITS 22
+#define ORL_HX_ONE_BITS 0x3C00u
+#define ORL_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#endif
+typedef hx_t hx4 __attribute__((ext_vector_type(4)));
+typedef hx_t hx8 __attribute__((ext_vector_type(8)));
+// static operand scales of the split multiply (powers of two; 1 in the bf16 build would do as well, they are exact either way)
+#define ORL_WSCALE 64.0f             // weight matrices (|w| < 1023): U(+-1/16)-sized weights land at O(1)
+#define ORL_WWSCALE 256.0f           // products w_tail[k] * W1[k][n] held by ws_dgrad_w0 (|.| < 255)
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+#ifdef ORL_SPLIT_BF16
+#define ORL_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)       // operands as s16x4 bit patterns
 // x = hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): twelve VALU instructions for four values (two packed
 // conversions per plane, the widening of hi back to fp32 done on the packed words) -- the element-wise form compiled to 20
-__device__ __forceinline__ void orl_split4(const f32x4& v, bf16x4& h, bf16x4& l) {
-  h = __builtin_convertvector(v, bf16x4);
+__device__ __forceinline__ void orl_split4(const f32x4& v, hx4& h, hx4& l) {
+  h = __builtin_convertvector(v, hx4);
   const u32x2_t hb = *(const u32x2_t*)&h;
   f32x4 hf;
   hf[0] = __uint_as_float(hb[0] << 16); hf[1] = __uint_as_float(hb[0] & 0xffff0000u);
   hf[2] = __uint_as_float(hb[1] << 16); hf[3] = __uint_as_float(hb[1] & 0xffff0000u);
-  l = __builtin_convertvector(v - hf, bf16x4);
+  l = __builtin_convertvector(v - hf, hx4);
 }
+#else
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#define ORL_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(*(const f16x4_t*)&(a), *(const f16x4_t*)&(b), c, 0, 0, 0)
+// x = hi + lo with hi = fp16(x) (round to nearest even, v_cvt_pk_f16_f32) and lo = fp16(x - hi); the remainder x - hi is exact in fp32
+__device__ __forceinline__ void orl_split4(const f32x4& v, hx4& h, hx4& l) {
+  h = __builtin_convertvector(v, hx4);
+  l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), hx4);
+}
+#endif
+__device__ __forceinline__ void orl_split1(float x, hx_t& h, hx_t& l) { h = (hx_t)x; l = (hx_t)(x - (float)h); }
 // bit j = (z[j] > 0): on the fp32 bit patterns read as signed integers, clamp(bits, 0, 1) is 1 exactly for positive non-zero values
 // (v_med3_i32; -0, +0 and negative values give 0) -- 7 instructions instead of 4 compares + 4 selects + 3 ors
 // ReLU in place + the 4 mask bits on the integer view of the floats: max(bits, 0) is ReLU (negative floats, -0 included, are negative
@@ -81,10 +117,10 @@ __device__ __forceinline__ unsigned int orl_mask4(const f32x4& z) {
 }
 #endif
 
-// precision of the multiply: P_F32 = v_mfma_f32_16x16x4_f32 (exact fp32);  P_BF16X3 = every operand split into
-// hi = bf16(x), lo = bf16(x - hi) while it is staged into LDS, product = lo*hi + hi*lo + hi*hi on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per operand, 3/16 of the fp32 MFMA cycles)
-enum { P_F32 = 0, P_BF16X3 = 1 };
+// precision of the multiply: P_F32 = v_mfma_f32_16x16x4_f32 (exact fp32);  P_SPLIT = every operand (times its power-of-two scale) split
+// into hi = half(x), lo = half(x - hi) while it is staged into LDS, product = lo*hi + hi*lo + hi*hi on the 16-bit MFMA with fp32
+// accumulation (22 significand bits per operand, 3/16 of the fp32 MFMA cycles), the scales divided out of the accumulators
+enum { P_F32 = 0, P_SPLIT = 1, P_BF16X3 = P_SPLIT };
 
 enum { PA_PLAIN = 0, PA_RANK1 = 1, PA_RANK1B = 2 };                    // prologue on A elements (RANK1B: ReLU mask from packed bits)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -146,6 +182,11 @@ struct GemmP {
   const unsigned int* a_bits; long ab_s0, ab_s1; int ab_g;
   ZPtr w0_x; long w0_xsr; int w0_in;
   float* w0_out; float* w0_bias; long w0_s0, w0_s1, w0_bs1, w0_ks, w0_sr;
+  // P_SPLIT operand scales (powers of two; 0 = 1): an element x of A enters the multiply as x * a_scale * (a_dscale ? a_dscale[z0] : 1),
+  // likewise B; the accumulators are divided by the product before the epilogue.  a_dscale / b_dscale: one float per run (z0) in device
+  // memory -- the scale k_grad_scale chose for the gradient matrices of the backward pass this operand belongs to.
+  float a_scale, b_scale;
+  const float* a_dscale; const float* b_dscale;
 };
 
 enum { W0_XP = 28 };     // LDS pitch of the X tile staged by the fused layer-0 weight gradient (floats)

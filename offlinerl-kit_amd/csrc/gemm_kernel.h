@@ -161,28 +161,28 @@ struct TileLoader {
     }
   }
 
-  // split-bf16 staging: hi plane at lds_h, lo plane ROWS*PITCH elements further
-  __device__ static inline void split4(const float* o, bf16x4& h, bf16x4& l) {
-    const f32x4 v = {o[0], o[1], o[2], o[3]};
+  // split staging: (element * sc) -> hi plane at lds_h, lo plane ROWS*PITCH elements further
+  __device__ static inline void split4(const float* o, float sc, hx4& h, hx4& l) {
+    const f32x4 v = {o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc};
     orl_split4(v, h, l);
   }
-  __device__ inline void store_split(__bf16* __restrict__ lds_h, int tid) const {
-    __bf16* lds_l = lds_h + ROWS * PITCH;
+  __device__ inline void store_split(hx_t* __restrict__ lds_h, int tid, float sc) const {
+    hx_t* lds_l = lds_h + ROWS * PITCH;
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       if (!EXACT && tid + i * NT >= NSLOTS) break;
       const float* o = &reg[i * SLOT_ELEMS];
       if (LMODE == L_SCALAR) {
-        const __bf16 hh = (__bf16)o[0];
-        lds_h[loff[i]] = hh; lds_l[loff[i]] = (__bf16)(o[0] - (float)hh);
+        hx_t hh, ll; orl_split1(o[0] * sc, hh, ll);
+        lds_h[loff[i]] = hh; lds_l[loff[i]] = ll;
       } else if (LMODE == L_VECK || LMODE == L_VECKU) {
-        bf16x4 h, l; split4(o, h, l);
-        *(bf16x4*)(lds_h + loff[i]) = h; *(bf16x4*)(lds_l + loff[i]) = l;
+        hx4 h, l; split4(o, sc, h, l);
+        *(hx4*)(lds_h + loff[i]) = h; *(hx4*)(lds_l + loff[i]) = l;
       } else {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          bf16x4 h, l; split4(o + rr * 4, h, l);
-          *(bf16x4*)(lds_h + loff[i] + rr * PITCH) = h; *(bf16x4*)(lds_l + loff[i] + rr * PITCH) = l;
+          hx4 h, l; split4(o + rr * 4, sc, h, l);
+          *(hx4*)(lds_h + loff[i] + rr * PITCH) = h; *(hx4*)(lds_l + loff[i] + rr * PITCH) = l;
         }
       }
     }
@@ -209,13 +209,13 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   constexpr int TM = CFG::TM, TN = CFG::TN, TK = CFG::kTK, NT = CFG::NT;
   constexpr int PITCH = (PREC == P_F32) ? CFG::PITCH : CFG::PITCH_H;   // LDS row pitch in elements of the plane type
   constexpr int MA = CFG::kMA, NB = CFG::kNB;
-  static_assert(PREC == P_F32 || TK % 32 == 0, "bf16 MFMA consumes 32 k per instruction");
+  static_assert(PREC == P_F32 || TK % 32 == 0, "the 16-bit MFMA consumes 32 k per instruction");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  // fp32: As [2][TM][PITCH] floats, Bs [2][TN][PITCH].   split-bf16: As [2][hi,lo][TM][PITCH] bf16, Bs likewise
+  // fp32: As [2][TM][PITCH] floats, Bs [2][TN][PITCH].   split: As [2][hi,lo][TM][PITCH] 16-bit planes, Bs likewise
   float* As = smem;
   float* Bs = smem + 2 * TM * PITCH;
-  __bf16* Ah = (__bf16*)smem;
-  __bf16* Bh = Ah + 2 * 2 * TM * PITCH;
+  hx_t* Ah = (hx_t*)smem;
+  hx_t* Bh = Ah + 2 * 2 * TM * PITCH;
 
   const int tid = threadIdx.x;
   const int z = blockIdx.z;
@@ -239,6 +239,12 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const float* __restrict__ Bg = p.B.at(z0, z1);
   const float* __restrict__ rowv = p.rowv.at(z0, z1);
   const float* __restrict__ colv = p.colv.at(z0, z1);
+  // P_SPLIT: power-of-two operand scales (GemmP::a_scale ..), uniform per workgroup
+  float sc_a = 1.f, sc_b = 1.f;
+  if (PREC != P_F32) {
+    sc_a = (p.a_scale != 0.f ? p.a_scale : 1.f) * (p.a_dscale ? p.a_dscale[z0] : 1.f);
+    sc_b = (p.b_scale != 0.f ? p.b_scale : 1.f) * (p.b_dscale ? p.b_dscale[z0] : 1.f);
+  }
 
   // K range of this split (chunk aligned); only the globally last chunk can be partial
   const int kchunks = (p.K + TK - 1) / TK;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 
   auto store_chunk = [&](int buf) {
     if (PREC == P_F32) { la.store(As + buf * TM * PITCH, tid); lb.store(Bs + buf * TN * PITCH, tid); }
-    else { la.store_split(Ah + buf * 2 * TM * PITCH, tid); lb.store_split(Bh + buf * 2 * TN * PITCH, tid); }
+    else { la.store_split(Ah + buf * 2 * TM * PITCH, tid, sc_a); lb.store_split(Bh + buf * 2 * TN * PITCH, tid, sc_b); }
   };
   if (kc_begin < kc_end) {
     load_chunk(kc_begin);
@@ -314,40 +320,40 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
         }
       }
     } else {
-      // lane (li, lq) supplies 8 consecutive k (8*lq ..) of row li for both operands of v_mfma_f32_16x16x32_bf16
-      const __bf16* ah = Ah + buf * 2 * TM * PITCH;
-      const __bf16* al = ah + TM * PITCH;
-      const __bf16* bh = Bh + buf * 2 * TN * PITCH;
-      const __bf16* bl = bh + TN * PITCH;
+      // lane (li, lq) supplies 8 consecutive k (8*lq ..) of row li for both operands of the 16x16x32 16-bit MFMA
+      const hx_t* ah = Ah + buf * 2 * TM * PITCH;
+      const hx_t* al = ah + TM * PITCH;
+      const hx_t* bh = Bh + buf * 2 * TN * PITCH;
+      const hx_t* bl = bh + TN * PITCH;
 #pragma unroll
       for (int kk = 0; kk < TK; kk += 32) {
-        bf16x8 fah[MA], fal[MA], fbh[NB], fbl[NB];
+        hx8 fah[MA], fal[MA], fbh[NB], fbl[NB];
 #pragma unroll
         for (int a = 0; a < MA; ++a) {
           const int o = (wrow0 + a * 16 + li) * PITCH + kk + 8 * lq;
-          fah[a] = *(const bf16x8*)&ah[o]; fal[a] = *(const bf16x8*)&al[o];
+          fah[a] = *(const hx8*)&ah[o]; fal[a] = *(const hx8*)&al[o];
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const int o = (wcol0 + b * 16 + li) * PITCH + kk + 8 * lq;
-          fbh[b] = *(const bf16x8*)&bh[o]; fbl[b] = *(const bf16x8*)&bl[o];
+          fbh[b] = *(const hx8*)&bh[o]; fbl[b] = *(const hx8*)&bl[o];
         }
 #pragma unroll
         for (int a = 0; a < MA; ++a)
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbl[b], fah[a], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fal[a], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[b], fah[a], acc[a][b], 0, 0, 0);
+            acc[a][b] = ORL_MFMA_16x16x32(fbl[b], fah[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbh[b], fal[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbh[b], fah[a], acc[a][b]);
           }
         if (EPI == E_WGRAD && want_bias) {
-          bf16x8 one;
+          hx8 one;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) one[j] = (__bf16)1.0f;
+          for (int j = 0; j < 8; ++j) one[j] = (hx_t)1.0f;
 #pragma unroll
           for (int a = 0; a < MA; ++a) {
-            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fal[a], accb[a], 0, 0, 0);
-            accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(one, fah[a], accb[a], 0, 0, 0);
+            accb[a] = ORL_MFMA_16x16x32(one, fal[a], accb[a]);
+            accb[a] = ORL_MFMA_16x16x32(one, fah[a], accb[a]);
           }
         }
       }
@@ -356,6 +362,15 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
     __syncthreads();
   }
 
+  if (PREC != P_F32) {                  // divide the operand scales out (exact: powers of two)
+    const float inv = 1.0f / (sc_a * sc_b), inv_a = 1.0f / sc_a;
+#pragma unroll
+    for (int a = 0; a < MA; ++a) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) acc[a][b] *= inv;
+      accb[a] *= inv_a;
+    }
+  }
   // ---- epilogue.  The MFMA was issued with the operands swapped (W-tile as A, X-tile as B), so the 16x16 block
   // lives transposed in the accumulators: lane (li, lq) holds C[m = li][n = 4*lq + reg], i.e. four CONSECUTIVE
   // output columns of one row -> one 16-byte store (and 16-byte bias / mask loads) per block instead of four

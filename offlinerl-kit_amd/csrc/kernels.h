@@ -54,6 +54,43 @@ struct Hyper {                          // mutable hyper-parameters (orl_set_lr)
 __global__ void k_tick(unsigned long long* gstep) { *gstep += 1ull; }
 
 // ------------------------------------------------------------------------------------------------
+// split precision: dynamic power-of-two scale of a backward pass.  The fp16 hi + lo planes of the split multiply cover 22 significand bits
+// only while hi = half(x * s) is a normal fp16 number, so the gradient matrices of one backward pass (its seed dL/d(tail output) and every
+// dz derived from it) enter the MFMAs times s = 2^(3 - floor(log2(max |seed|))): the seed's largest entry lands in [8, 16), which leaves
+// 2^12 of headroom for the growth of a dz through the layers below and 2^-17 of room below before an entry's hi plane turns subnormal
+// (it then still carries 2^-24 absolute = 2^-27 of the largest entry).  One workgroup per run; max over every net's seed; exact.
+// ------------------------------------------------------------------------------------------------
+struct GradScaleP { const float* seed; long rs, cs; int rows, cols, pitch, nets; float* out; };
+__global__ void k_grad_scale(GradScaleP p) {
+  __shared__ float sh[256];
+  const int r = blockIdx.x;
+  const float* base = p.seed + (long)r * p.rs;
+  const long per_net = (long)p.rows * p.cols, n = per_net * p.nets;
+  float m = 0.f;
+  for (long e = threadIdx.x; e < n; e += 256) {
+    const long z = e / per_net, w = e - z * per_net;
+    const long row = w / p.cols, c = w - row * p.cols;
+    m = fmaxf(m, fabsf(base[z * p.cs + row * p.pitch + c]));      // fmaxf drops NaNs: a diverged run keeps scale 1 and shows its NaNs in the losses
+  }
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float a = sh[0];
+    float s = 1.f;
+    if (a > 0.f && a < 3.0e38f) {
+      int e = ilogbf(a);
+      e = e < -100 ? -100 : (e > 100 ? 100 : e);
+      s = ldexpf(1.0f, 3 - e);
+    }
+    p.out[r] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // replay gather (buffer.py:96-106).  Dataset = SoA in HBM, rows padded to 16 B (obs/next_obs pitch OP,
 // act pitch AP).  idx == nullptr -> Philox indices (np.random.randint(0, size, B) restated on device).
 // One thread per (row, column) of the widest array; consecutive lanes read consecutive floats of a row

@@ -4,10 +4,8 @@
 
 namespace orl {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-
-__device__ inline void ws_split8(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
-  bf16x4 ha, la, hb, lb;
+__device__ inline void ws_split8(const f32x4& a, const f32x4& b, hx8& h, hx8& l) {
+  hx4 ha, la, hb, lb;
   orl_split4(a, ha, la);
   orl_split4(b, hb, lb);
   h = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);

@@ -7,8 +7,8 @@ template <bool W0, bool STORE>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
-  __bf16* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
+  hx_t* Ah = (hx_t*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
+  hx_t* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
   float* EO = (float*)(XT + 2 * 2 * 32 * WD_XP);                   // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]: epilogue operands
   __shared__ u32x2_t mlut[16];                                     // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
@@ -20,9 +20,14 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
   const int ncol0 = 32 * wave;
+  // split precision: dq enters scaled by the run's dynamic gradient scale (W0 variant only: the stored dz0 of the STORE variant must be
+  // the true values), the resident products by ORL_WWSCALE; dz0 therefore carries gs * ORL_WWSCALE into the second MFMA stage
+  const float gsc = (W0 && p.gscale) ? p.gscale[z0] : 1.f;
+  const float dq_sc = W0 ? gsc : 1.0f / ORL_WWSCALE;                // factor applied to dq when it is staged
+  const float out_inv = 1.0f / (gsc * ORL_WWSCALE);                  // W0: applied to the dW0 / db0 slab
 
   // resident B' fragments: lane (li, lq) supplies B'[k = 32 ks + 8 lq + j][n = ncol0 + 16 cb + li] = w_tail[k] * W1[k][n]
-  bf16x8 bh[2][8], bl[2][8];
+  hx8 bh[2][8], bl[2][8];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
@@ -32,14 +37,14 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       f32x4 a, b;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        a[j] = t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
-        b[j] = t1[j] * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
+        a[j] = (t0[j] * ORL_WWSCALE) * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];       // static scale, divided out below
+        b[j] = (t1[j] * ORL_WWSCALE) * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
       }
       ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
     }
   // zero both X^T images once (rows c >= x_pitch are never written again)
   if (W0) for (int e = tid; e < 2 * 2 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
-  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * 0x3F80u, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * 0x3F80u};
+  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
   __syncthreads();
 
   // ---- staging of one row group: thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
@@ -85,20 +90,21 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     const u32x2_t q0 = mlut[bits & 15u], q1 = mlut[(bits >> 4) & 15u], q2 = mlut[(bits >> 8) & 15u], q3 = mlut[bits >> 12];
     c0 = (u32x4){q0[0], q0[1], q1[0], q1[1]};
     c1 = (u32x4){q2[0], q2[1], q3[0], q3[1]};
-    __bf16* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
+    hx_t* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
     float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
-    eo[tid & 31] = sdq;                                              // (replicated writes of identical values)
+    eo[tid & 31] = sdq * dq_sc;                                      // (replicated writes of identical values)
     ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
-    __bf16* xt = XT + (long)buf * 2 * 32 * WD_XP;
+    hx_t* xt = XT + (long)buf * 2 * 32 * WD_XP;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (W0) {
         const float x = (xo[i] >> 16) ? 1.0f : sx[i];
-        const __bf16 hh = (__bf16)x;
+        hx_t hh, ll;
+        orl_split1(x, hh, ll);
         xt[xo[i] & 0xFFFF] = hh;
-        xt[32 * WD_XP + (xo[i] & 0xFFFF)] = (__bf16)(x - (float)hh);
+        xt[32 * WD_XP + (xo[i] & 0xFFFF)] = ll;
       }
     }
   };
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) xw[s][r] = w4[r];
     }
-    const __bf16* ah = Ah + (long)buf * WS_ROWS * WS_PITCH;
+    const hx_t* ah = Ah + (long)buf * WS_ROWS * WS_PITCH;
     f32x4 acc[WS_SUB][2];
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s)
@@ -140,17 +146,17 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
-        const bf16x8 fa = *(const bf16x8*)&ah[(16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3)];
+        const hx8 fa = *(const hx8*)&ah[(16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3)];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {               // D[m][n]: lane holds rows 4 lq + r of column li
-          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bl[cb][ks], acc[s][cb], 0, 0, 0);
-          acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, bh[cb][ks], acc[s][cb], 0, 0, 0);
+          acc[s][cb] = ORL_MFMA_16x16x32(fa, bl[cb][ks], acc[s][cb]);
+          acc[s][cb] = ORL_MFMA_16x16x32(fa, bh[cb][ks], acc[s][cb]);
         }
       }
     }
     // dz0 block -> (hi, lo) bf16 B operand of the 16x16x16 MFMA; A operand = X^T rows c, columns m = 16 s + 4 lq ..
-    const __bf16* xth = XT + (long)buf * 2 * 32 * WD_XP;
-    const __bf16* xtl = xth + 32 * WD_XP;
+    const hx_t* xth = XT + (long)buf * 2 * 32 * WD_XP;
+    const hx_t* xtl = xth + 32 * WD_XP;
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
       s16x4 xh[2], xl[2];
@@ -163,21 +169,22 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
       }
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        bf16x4 zh, zl;
+        hx4 zh, zl;
         // (element by element: gathering the four values first and splitting them with orl_split4 measured 15 % slower here)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4[s][r] : 0.f;
           if (STORE) Cg[(long)(g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + 16 * cb + li] = v;
-          const __bf16 hh = (__bf16)v;
-          zh[r] = hh; zl[r] = (__bf16)(v - (float)hh);
+          hx_t hh, ll;
+          orl_split1(v, hh, ll);
+          zh[r] = hh; zl[r] = ll;
         }
         const s16x4 bzh = *(const s16x4*)&zh, bzl = *(const s16x4*)&zl;
 #pragma unroll
         for (int cbk = 0; cbk < 2 && W0; ++cbk) {
-          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xl[cbk], bzh, d2[cbk][cb], 0, 0, 0);
-          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzl, d2[cbk][cb], 0, 0, 0);
-          d2[cbk][cb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(xh[cbk], bzh, d2[cbk][cb], 0, 0, 0);
+          d2[cbk][cb] = ORL_MFMA_16x16x16(xl[cbk], bzh, d2[cbk][cb]);
+          d2[cbk][cb] = ORL_MFMA_16x16x16(xh[cbk], bzl, d2[cbk][cb]);
+          d2[cbk][cb] = ORL_MFMA_16x16x16(xh[cbk], bzh, d2[cbk][cb]);
         }
       }
     }
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * cbk + 4 * lq + r, n = ncol0 + 16 * cb + li;
-        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r];
-        else if (c == p.in0) bo[n] = d2[cbk][cb][r];
+        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r] * out_inv;
+        else if (c == p.in0) bo[n] = d2[cbk][cb][r] * out_inv;
       }
 }
 

@@ -10,7 +10,7 @@ namespace orl {
 template <bool TQ, bool L0, bool DG = false, bool SY = true, bool F32 = false>      // SY = false: the activation itself is not stored (TQ only)
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  __bf16* Ah = (__bf16*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
+  hx_t* Ah = (hx_t*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
   float* Af = ws_smem;                                             // F32: [buf][row][WS_K]
   float* qs = ws_smem + (2 * 2 * WS_ROWS * WS_PITCH * 2) / 4;       // [parity][wave][row]
   unsigned char* nbs = (unsigned char*)(qs + 2 * WS_NW * WS_ROWS);       // [parity][row][64]: 4 mask bits per (row, 4 columns)
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
   // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
   // F32: lane (li, lq) supplies W[n][k = 16 t + 4 lq .. + 3], t = 0..15 (element e of the float4 = MFMA k step e of block t)
-  bf16x8 bh[WS_CB][F32 ? 1 : 8], bl[WS_CB][F32 ? 1 : 8];
+  hx8 bh[WS_CB][F32 ? 1 : 8], bl[WS_CB][F32 ? 1 : 8];
   f32x4 bw[WS_CB][F32 ? 16 : 1];
   if constexpr (F32) {
 #pragma unroll
@@ -49,17 +49,18 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
-      if (p.w_sk == 1) ws_split8(*(const f32x4*)src, *(const f32x4*)(src + 4), bh[cb][ks], bl[cb][ks]);
+      // the resident weights carry the static scale ORL_WSCALE (divided out in the epilogue): hi stays in fp16's normal range
+      if (p.w_sk == 1) ws_split8(*(const f32x4*)src * ORL_WSCALE, *(const f32x4*)(src + 4) * ORL_WSCALE, bh[cb][ks], bl[cb][ks]);
       else {                                           // (in, out)-major weights: eight strided loads, once per workgroup
         f32x4 a, b;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = src[(long)j * p.w_sk]; b[j] = src[(long)(4 + j) * p.w_sk]; }
+        for (int j = 0; j < 4; ++j) { a[j] = src[(long)j * p.w_sk] * ORL_WSCALE; b[j] = src[(long)(4 + j) * p.w_sk] * ORL_WSCALE; }
         ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
       }
     }
   }
   // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
-  bf16x8 b0h[WS_CB], b0l[WS_CB];
+  hx8 b0h[WS_CB], b0l[WS_CB];
   f32x4 b0w[WS_CB][2];                              // F32: k = 16 t + 4 lq + e
   if (L0) {
     const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
@@ -92,6 +93,9 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
   if (!DG && tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }      // visible after the prologue's barriers
   const float tbias = TQ ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
+  // split precision: the accumulators carry ORL_WSCALE (weights) and, in gradient mode, the run's dynamic gradient scale (staged rows)
+  const float a_sc = (DG && !F32 && p.gscale) ? p.gscale[z0] : 1.f;
+  const float inv_sc = F32 ? 1.f : 1.0f / (ORL_WSCALE * a_sc);
 
   // ---- staging of one row group: thread t moves float4 #(t + 512 i), i = 0..7, of the [64][256] tile ----
   // one staging register set: refilled with group g + 2 gs right after group g + gs has been written to LDS
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     st[i] = *(const f32x4*)&Xg[(long)m * p.x_pitch + 4 * kq];
   };
   auto store_group = [&](int buf, const f32x4 (&st)[WS_LD], int i0 = 0, int i1 = WS_LD) __attribute__((always_inline)) {
-    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
-    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+    hx_t* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    hx_t* dl = dh + WS_ROWS * WS_PITCH;
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
       const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
@@ -119,13 +123,13 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
         *(f32x4*)(Af + (long)buf * WS_ROWS * WS_K + r * WS_K + ((kq ^ (r & 15)) << 2)) = st[i];
         continue;
       }
-      bf16x4 h, l;
-      orl_split4(st[i], h, l);
+      hx4 h, l;
+      if (DG) orl_split4(st[i] * a_sc, h, l); else orl_split4(st[i], h, l);
       // 16-byte chunk c = k / 8 of row r lives at chunk c ^ (r & 15): ds_read_b128 of a fragment column is then conflict-free
       // for the hardware's 16-lane groups (which mix lanes of two neighbouring chunks), and these 8-byte stores stay so too
       const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
-      *(bf16x4*)(dh + o) = h;
-      *(bf16x4*)(dl + o) = l;
+      *(hx4*)(dh + o) = h;
+      *(hx4*)(dl + o) = l;
     }
   };
 
@@ -152,28 +156,29 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       const float x = (xc[i] == p.in0) ? 1.0f : sx[i];
       if constexpr (F32) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = x;   // surplus threads: pad column 32
       else {
-        __bf16* row = (__bf16*)(Xl + (buf * WS_ROWS + xr[i]) * WS_XLP);
+        hx_t* row = (hx_t*)(Xl + (buf * WS_ROWS + xr[i]) * WS_XLP);
         const bool pad = xc[i] >= 32;
-        const __bf16 hh = (__bf16)x;
+        hx_t hh, ll;
+        orl_split1(x, hh, ll);
         row[pad ? 64 : xc[i]] = hh;
-        row[pad ? 65 : 32 + xc[i]] = (__bf16)(x - (float)hh);
+        row[pad ? 65 : 32 + xc[i]] = ll;
       }
     }
   };
   // produce(g): h0 rows of group g for this wave's columns -> global (fp32), the LDS image `buf` (split bf16), mask nibbles
   f32x4 fx32[2];                                     // F32: the narrow-input fragments of prod_x (k = 16 t + 4 lq + e)
-  auto prod_x = [&](int xbuf, int s, bf16x8& xah, bf16x8& xal) __attribute__((always_inline)) {
+  auto prod_x = [&](int xbuf, int s, hx8& xah, hx8& xal) __attribute__((always_inline)) {
     if constexpr (F32) {
       const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 4 * lq;
       fx32[0] = *(const f32x4*)xrow; fx32[1] = *(const f32x4*)(xrow + 16);
     } else {
-      const __bf16* xrow = (const __bf16*)(Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP) + 8 * lq;
-      xah = *(const bf16x8*)xrow; xal = *(const bf16x8*)(xrow + 32);
+      const hx_t* xrow = (const hx_t*)(Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP) + 8 * lq;
+      xah = *(const hx8*)xrow; xal = *(const hx8*)(xrow + 32);
     }
   };
-  auto prod_block = [&](int g, int buf, int par, int s, int cb, const bf16x8& xah, const bf16x8& xal) __attribute__((always_inline)) {
-    __bf16* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
-    __bf16* dl = dh + WS_ROWS * WS_PITCH;
+  auto prod_block = [&](int g, int buf, int par, int s, int cb, const hx8& xah, const hx8& xal) __attribute__((always_inline)) {
+    hx_t* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    hx_t* dl = dh + WS_ROWS * WS_PITCH;
     const int r = 16 * s + li;
     const long m = (long)g * WS_ROWS + r;
     f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -183,9 +188,9 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_mfma_f32_16x16x4f32(b0w[cb][t][e], fx32[t][e], v, 0, 0, 0);
     } else {
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0l[cb], xah, v, 0, 0, 0);
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xal, v, 0, 0, 0);
-      v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0h[cb], xah, v, 0, 0, 0);
+      v = ORL_MFMA_16x16x32(b0l[cb], xah, v);
+      v = ORL_MFMA_16x16x32(b0h[cb], xal, v);
+      v = ORL_MFMA_16x16x32(b0h[cb], xah, v);
     }
     const unsigned int nib0 = orl_relu_mask4(v);
     const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
@@ -193,18 +198,18 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     if constexpr (F32) {
       *(f32x4*)(Af + (long)buf * WS_ROWS * WS_K + r * WS_K + (((k >> 2) ^ (r & 15)) << 2)) = v;
     } else {
-    bf16x4 h, l;
+    hx4 h, l;
     orl_split4(v, h, l);
     const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
-    *(bf16x4*)(dh + o) = h;
-    *(bf16x4*)(dl + o) = l;
+    *(hx4*)(dh + o) = h;
+    *(hx4*)(dl + o) = l;
     }
     nbs0[(par * WS_ROWS + r) * WS_NBP + (k >> 2)] = (unsigned char)nib0;
   };
   auto produce = [&](int g, int buf, int xbuf, int par) __attribute__((always_inline)) {
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      bf16x8 xah, xal;
+      hx8 xah, xal;
       prod_x(xbuf, s, xah, xal);
 #pragma unroll
       for (int cb = 0; cb < WS_CB; ++cb) prod_block(g, buf, par, s, cb, xah, xal);
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   auto epi_block = [&](const f32x4& a, int g, int par, int s, int cb, float& part) __attribute__((always_inline)) {
     const f32x4 bq = *(const f32x4*)&cst[ncol0 + 16 * cb + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol0 + 16 * cb + 4 * lq];
     const int m = g * WS_ROWS + 16 * s + li;
-    f32x4 v = a + bq;
+    f32x4 v = F32 ? a + bq : a * inv_sc + bq;
     const unsigned int nib = orl_relu_mask4(v);
     if (storeY) *(f32x4*)&Yg[(long)m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
     part += (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
           const unsigned int nib = w >> (16 * cb + 4 * lq);
           f32x4 v = acc[s][cb];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] : 0.f;
+          for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? (F32 ? v[r] : v[r] * inv_sc) : 0.f;
           *(f32x4*)&Yg[m * p.y_pitch + ncol0 + 16 * cb + 4 * lq] = v;
         }
       }
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   // steady = true: groups g + gs .. g + 3 gs exist, so the body has no conditionals (one basic block up to the barrier)
   auto iteration = [&](int g, int it, f32x4 (&stn)[WS_LD], bool first, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
-    const __bf16* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
-    const __bf16* al = ah + WS_ROWS * WS_PITCH;
+    const hx_t* ah = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+    const hx_t* al = ah + WS_ROWS * WS_PITCH;
     f32x4 acc[WS_SUB][WS_CB];
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s)
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool fine = steady && !DG;
     float fpart = 0.f;
-    bf16x8 fxah, fxal;
+    hx8 fxah, fxal;
     // Steady state: the work of the other pipeline stages is cut into eight pieces, one per k step, and fenced together with that
     // step's 12 MFMAs -- the default scheduler otherwise clusters all 96 MFMAs and the matrix pipe idles during the epilogue /
     // staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue; 4..7: the four blocks of the next
@@ -368,24 +373,24 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
                 acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(bw[cb][2 * ks + tt][e], fa[s][e], acc[s][cb], 0, 0, 0);
         }
       } else {
-      bf16x8 fah2[WS_SUB], fal2[WS_SUB];
+      hx8 fah2[WS_SUB], fal2[WS_SUB];
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
         const int o = (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3);
-        fah2[s] = *(const bf16x8*)&ah[o]; fal2[s] = *(const bf16x8*)&al[o];
+        fah2[s] = *(const hx8*)&ah[o]; fal2[s] = *(const hx8*)&al[o];
       }
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
-        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(bl[cb][ks], fah2[s], acc[s][cb]);
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
-        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fal2[s], acc[s][cb], 0, 0, 0);
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(bh[cb][ks], fal2[s], acc[s][cb]);
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
-        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[cb][ks], fah2[s], acc[s][cb], 0, 0, 0);
+        for (int cb = 0; cb < WS_CB; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(bh[cb][ks], fah2[s], acc[s][cb]);
       }
       if (fine) {
         piece(ks);
@@ -459,10 +464,10 @@ static void ws_fwd_dispatch(const WsFwdP& p, dim3 grid, dim3 block, size_t lds, 
   }
 }
 
-hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st) {
+hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st, const WsGeom& geo) {
   p.groups = (p.M + WS_ROWS - 1) / WS_ROWS;
   // one workgroup per CU (register-resident weights): whole rounds of 256 workgroups over the nz problems (ws_blocks_per_problem)
-  const int per_z = ws_blocks_per_problem(p.groups, nz, 10, 1 << 20);
+  const int per_z = ws_blocks_per_problem(p.groups, nz, 10, 1 << 20, geo);
   const size_t lds = ws_fwd_lds_bytes(p.X0 != nullptr);
   static const hipError_t attr_err = [] {       // thread-safe one-time initialisation (engines may launch from several host threads)
     hipError_t e = ws_fwd_attrs<false>();

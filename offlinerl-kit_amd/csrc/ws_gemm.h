@@ -3,21 +3,22 @@
 // The generic tile kernel (gemm.h) spends about half of a workgroup's lifetime in its prologue / epilogue when K is
 // only 256 (eight K chunks per tile) and re-reads the weight tile for every row tile.  For the hot shapes of the
 // update engine (hidden layers of width 256 evaluated on thousands of rows: CQL's 7936-row critic batch, reference
-// cql.py:132-190) the whole weight matrix fits in ONE CU's register file once it is split into bf16 hi/lo planes
+// cql.py:132-190) the whole weight matrix fits in ONE CU's register file once it is split into 16-bit hi/lo planes
 // (256 x 256 x 4 B = 256 KB of the 512 KB VGPR file).  So:
 //
 //   * a workgroup = 8 waves; wave w owns output columns [32w, 32w+32) and keeps the B fragments of those columns for
 //     the complete K = 256 in registers (2 column blocks x 8 k-steps x {hi, lo} x 4 VGPRs = 128 VGPRs), loaded and
 //     split ONCE per workgroup;
-//   * the workgroup then streams row groups of 64 rows: the fp32 rows are fetched with full-row coalesced loads,
-//     split into bf16 hi/lo while they are staged into a double-buffered LDS image, and every wave multiplies the
-//     shared A fragments against its resident B fragments (v_mfma_f32_16x16x32_bf16, lo*hi + hi*lo + hi*hi, fp32
-//     accumulation) -- one barrier per 64 rows, no per-tile pipeline fill / drain, no weight traffic in the loop;
+//   * the workgroup then streams row groups of WS_ROWS = 32 rows: the fp32 rows are fetched with full-row coalesced loads,
+//     split into 16-bit hi/lo planes while they are staged into a double-buffered LDS image, and every wave multiplies the
+//     shared A fragments against its resident B fragments (16x16x32 16-bit MFMA, lo*hi + hi*lo + hi*hi, fp32
+//     accumulation) -- one barrier per row group, no per-tile pipeline fill / drain, no weight traffic in the loop;
 //   * the epilogue works on the wave's own 16 x 32 accumulator blocks (bias, ReLU, packed ReLU-mask bits, the fused
 //     single-output tail q = h . w_tail + b_tail), so it needs no LDS round trip.
 //
-// Per row group and CU: 64 KB of HBM reads against 2 x 192 MFMAs per SIMD (6144 cycles), i.e. the kernel sits at the
-// crossover of the HBM and matrix-pipe rooflines instead of far below both.
+// Per row group and CU: 32 KB of HBM reads against 2 x 96 (+ 12 with the fused first layer) MFMAs per SIMD (~3460 matrix-pipe cycles;
+// measured ~6200 cycles per group with the vector work), i.e. the kernel sits at the crossover of the HBM and
+// matrix-pipe rooflines instead of far below both.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -47,7 +48,8 @@ struct WsFwdP {
   // plain dgrad mode (template DG): Y = (X B^T) (.) mask, B given by the strides above (W viewed transposed), no bias / ReLU / mask
   // emission; `dmask` = packed ReLU mask of the activation the gradient flows into
   const unsigned int* dmask; long dm_s0, dm_s1; int dm_g;
-  int f32;                                              // exact fp32 arithmetic (v_mfma_f32_16x16x4_f32) instead of split bf16
+  int f32;                                              // exact fp32 arithmetic (v_mfma_f32_16x16x4_f32) instead of the split 16-bit planes
+  const float* gscale;                                  // DG, split precision: dynamic power-of-two scale of the gradient rows X, one float per run (z0); null = 1
 };
 
 #ifndef WS_WAVES
@@ -63,13 +65,11 @@ static constexpr size_t ws_fwd_lds_bytes(bool l0 = false) {
          (l0 ? sizeof(float) * 2 * WS_ROWS * WS_XLP + 2 * WS_ROWS * WS_NBP : 0) + sizeof(float) * 2 * WS_N;   // + bias / tail weights
 }
 
-// host: does the launch qualify?  (split-bf16 precision, K = N = 256, 16-byte aligned operands)
-// CUs one weight-stationary launch spreads over (one workgroup per CU).  ORL_WS_CUS < 256 leaves room for the launches of other
-// engines' streams to run side by side instead of one after the other.
-static inline int ws_cu_budget() {
-  static const int v = [] { const char* f = getenv("ORL_WS_CUS"); const int x = f ? atoi(f) : 0; return (x >= 8 && x <= 256) ? x : 256; }();
-  return v;
-}
+// host: does the launch qualify?  (K = N = 256, 16-byte aligned operands)
+// Launch geometry of one engine's weight-stationary kernels (orl_config::ws_one_round / ws_cus; the ORL_WS_ONE_ROUND / ORL_WS_CUS
+// environment variables override them once, at engine creation).  `cus` < 256 leaves room for the launches of other engines' streams to
+// run side by side instead of one after the other.
+struct WsGeom { int cus = 256; bool one_round = false; };
 
 // Workgroups per problem (net).  One workgroup occupies a CU (512 threads x 256 VGPRs), so a launch runs in ROUNDS of 256 workgroups.
 // With `nz` problems of `groups` row groups each, `per_z` workgroups per problem take ceil(nz * per_z / CUs) rounds of
@@ -78,17 +78,15 @@ static inline int ws_cu_budget() {
 // `prologue` = the per-workgroup fixed cost in units of one row group (resident-operand load + pipeline fill: ~10 for the forward /
 // dgrad kernels; the output-stationary wgrad passes a prohibitive value: its per-workgroup slab write and derived tail gradients cost what
 // the idle CUs cost).  Measured, one engine x 96 runs: forward 772 -> 622 us, dgrad 520 -> 439 us, 39.3k -> 41.7k steps/s.
-// ORL_WS_ONE_ROUND=1 restores the old rule: with TWO engines per GPU the idle CUs of one engine's launch are where the other engine's
-// kernels run, and filling them costs more than it gains (2 x 96 runs: 48.0k one round, 44.3k whole rounds) -- bench.py sets it then.
-static inline int ws_blocks_per_problem(int groups, int nz, int prologue, int cap) {
-  const int cus = ws_cu_budget();
-  const char* f = getenv("ORL_WS_ONE_ROUND");          // read per launch decision (graph capture time), so a process can hold engines of both kinds
-  const bool one_round = f && atoi(f) != 0;
+// one_round restores the old rule: with TWO engines per GPU the idle CUs of one engine's launch are where the other engine's kernels
+// run, and filling them costs more than it gains (2 x 96 runs: 48.0k one round, 44.3k whole rounds) -- bench.py asks for it then.
+static inline int ws_blocks_per_problem(int groups, int nz, int prologue, int cap, const WsGeom& geo) {
+  const int cus = geo.cus;
   int base = cus / nz;
   if (base < 1) base = 1;
   if (base > groups) base = groups;
   if (base > cap) base = cap;
-  if (one_round) return base;
+  if (geo.one_round) return base;
   int best = base;
   long best_cost = (long)((nz * (long)base + cus - 1) / cus) * (prologue + (groups + base - 1) / base);
   for (int pz = base + 1; pz <= 4 * base + 4 && pz <= groups && pz <= cap; ++pz) {
@@ -114,7 +112,7 @@ static inline bool ws_fwd01_supported(const WsFwdP& p) {      // extra condition
   if (!p.X0 || !p.mb0 || p.mb0_g != 8 || p.in0 + 1 > 32 || p.in0 >= p.x0_pitch || p.x0_pitch > 32 || WS_ROWS * p.x0_pitch > 2 * WS_NT) return false;
   return true;
 }
-hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st);      // ws_fwd.hip
+hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st, const WsGeom& geo);      // ws_fwd.hip
 
 // =====================================================================================================================
 // ws_dgrad_w0: backward through the top hidden layer of a single-output net, fused with the layer-0 weight gradient.
@@ -142,7 +140,8 @@ struct WsDgradP {
   float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
   int M, nz1, groups;
-  int f32;                                                     // exact fp32 arithmetic (ws_dgrad32_w0_kernel) instead of split bf16
+  int f32;                                                     // exact fp32 arithmetic (ws_dgrad32_w0_kernel) instead of the split 16-bit planes
+  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq, one float per run (z0); null = 1
 };
 enum { WD_XP = WS_ROWS + 4 };                                       // bf16 pitch of an X^T row (72 B: scattered 2-byte stores and 8-byte reads spread over the banks)
 static constexpr size_t ws_dgrad_lds_bytes() {     // mask images + X^T images + per-group epilogue operands (dq, h0 mask words)
@@ -158,8 +157,8 @@ static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
   return true;
 }
 // blocks per problem (= split-K slabs written per problem)
-static inline int ws_dgrad_blocks(int M, int nz, int max_slab, int prologue = 10) {
-  return ws_blocks_per_problem(M / WS_ROWS, nz, prologue, max_slab);
+static inline int ws_dgrad_blocks(int M, int nz, int max_slab, const WsGeom& geo, int prologue = 10) {
+  return ws_blocks_per_problem(M / WS_ROWS, nz, prologue, max_slab, geo);
 }
 hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st);      // ws_dgrad.hip
 
@@ -196,7 +195,8 @@ struct WsWgradP {
   const float* W1; long w1_s0, w1_s1;                          // [256][256] (out, in) row-major
   const float* b1; long b1_s0, b1_s1;
   int M, nz1, groups;
-  int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of split bf16
+  int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of the split 16-bit planes
+  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq, one float per run (z0); null = 1
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
 static constexpr size_t ws_wgrad_lds_bytes() { return (size_t)2 * 3 * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2; }   // 2 buffers x {mask, G hi, G lo} + dq blocks

@@ -9,11 +9,11 @@ namespace orl {
 // slower at 128 runs: 581 vs 569 us)
 __device__ inline int ww_off(int r, int chunk, int half) { return r * WS_K + ((chunk ^ (2 * (r & 7))) << 3) + (half << 2); }
 
-__device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
+__device__ inline s16x4 ww_tr(const hx_t* img, int row0, int col0, int lane) {
   // 16-lane group lq reads rows row0 + 4 lq + q (q = li >> 2), columns col0 + 4 (li & 3) ..; lane li receives column col0 + li of
   // rows row0 + 4 lq .. + 3  (= the 16x16x16 MFMA operand layout, for A as the transpose of the image)
   const int li = lane & 15, lq = lane >> 4, row = row0 + 4 * lq + (li >> 2), col = col0 + 4 * (li & 3);
-  const __bf16* a = img + ww_off(row, col >> 3, (col >> 2) & 1);
+  const hx_t* a = img + ww_off(row, col >> 3, (col >> 2) & 1);
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)a);
 }
 
@@ -21,9 +21,10 @@ __device__ inline s16x4 ww_tr(const __bf16* img, int row0, int col0, int lane) {
 // the tail layer's gradients (streamed or derived).  `smem` = the kernel's LDS (the operand images are dead by now).
 template <int MODE>
 __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, const f32x4 (&acc)[16][2], const f32x4 (&accb)[2], const f32x4& tacc,
-                                          const f32x4& bacc, float dqsum, const float* __restrict__ wtg, int z0, int z1, int ncol0) {
+                                          const f32x4& bacc, float dqsum, const float* __restrict__ wtg, int z0, int z1, int ncol0, float inv = 1.0f) {
   constexpr bool TAILS = (MODE == 1);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  // `inv`: the MFMA accumulators (acc, accb) carry the dynamic gradient scale of the split-precision kernel; tacc / bacc / dqsum do not
   // ---- one slab per workgroup ----
   const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
   float* dW = p.dW + so + z1 * p.o_s1w;
@@ -34,7 +35,7 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = w4[r] * acc[kb][nb][r];
+      for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = (w4[r] * inv) * acc[kb][nb][r];
   }
   if (MODE == 2) {
     // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
@@ -46,7 +47,7 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int o = 16 * kb + 4 * lq + r;
-        float t = W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r];
+        float t = (W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r]) * inv;
         t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
         if (li == 0) red[wave * WS_K + o] = t;
       }
@@ -54,7 +55,7 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r];
+        for (int r = 0; r < 4; ++r) red[8 * WS_K + 16 * (2 * wave + x) + 4 * lq + r] = accb[x][r] * inv;
     }
     if (lane == 0) red[9 * WS_K + wave] = dqsum;
     __syncthreads();
@@ -80,7 +81,7 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
       for (int x = 0; x < 2; ++x) {
         const int k0 = 16 * (2 * wave + x) + 4 * lq;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * accb[x][r];
+        for (int r = 0; r < 4; ++r) db[k0 + r] = wtg[k0 + r] * (accb[x][r] * inv);
       }
     }
     return;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
   constexpr bool TAILS = (MODE == 1);
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  __bf16* img = (__bf16*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
+  hx_t* img = (hx_t*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
   __shared__ u32x2_t mlut[16];                                      // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   const float* __restrict__ H0g = p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1;
   const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const int ncol0 = 32 * wave;
+  // split precision: G = (dq * gs) (.) h0 with the run's dynamic power-of-two gradient scale gs, divided out of the slab in ww_finish
+  const float gsc = p.gscale ? p.gscale[z0] : 1.f;
 
   f32x4 acc[16][2], accb[2];
 #pragma unroll
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
   float sdq[4];
   unsigned int sm_word;
-  __bf16* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
+  hx_t* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
   // Global addresses = (uniform part: row group and piece, scalar ALU) + (per-thread part, computed once): the loop carries no vector
   // address arithmetic (64-bit multiplies cost a SIMD 4 - 7 cycles each, and vector instructions do not overlap with its MFMAs).
   const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) load_piece(g, i);
   };
   auto store_mask = [&](int buf) __attribute__((always_inline)) {
-    __bf16* mi = img + (long)buf * 3 * WW_IMG;
+    hx_t* mi = img + (long)buf * 3 * WW_IMG;
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     u32x4 c0, c1;
@@ -171,22 +174,24 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     *(u32x4*)(mi + ww_off(r, 2 * hw + 1, 0)) = c1;
   };
   auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
-    __bf16* gh = img + (long)buf * 3 * WW_IMG + WW_IMG;
-    __bf16* gl = gh + WW_IMG;
+    hx_t* gh = img + (long)buf * 3 * WW_IMG + WW_IMG;
+    hx_t* gl = gh + WW_IMG;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
-    bf16x4 h, l;
-    orl_split4(s0[i] * sdq[i], h, l);
+    hx4 h, l;
+    const float dqs = sdq[i] * gsc;
+    orl_split4(s0[i] * dqs, h, l);
     const int o = ww_off(r, kq >> 1, kq & 1);
-    *(bf16x4*)(gh + o) = h;
-    *(bf16x4*)(gl + o) = l;
+    *(hx4*)(gh + o) = h;
+    *(hx4*)(gl + o) = l;
     if (TAILS) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { tacc[j] += sdq[i] * s1[i][j]; bacc[j] += s1[i][j] > 0.f ? sdq[i] : 0.f; }
       dqsum += sdq[i];
     } else if (kq == 0) {                                            // this row's dq into the bias-gradient operand block
-      const __bf16 hh = (__bf16)sdq[i];
-      __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
-      dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = (__bf16)(sdq[i] - (float)hh);
+      hx_t hh, ll;
+      orl_split1(dqs, hh, ll);
+      hx_t* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
+      dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = ll;
       if (MODE == 2) dqsum += sdq[i];
     }
   };
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
   if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
-  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * 0x3F80u, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * 0x3F80u};
+  if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
   __syncthreads();
 
   const int g0 = blockIdx.x, gs = gridDim.x;
@@ -211,19 +216,19 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
     const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
-    const __bf16* mi = img + (long)buf * 3 * WW_IMG;
-    const __bf16* gh = mi + WW_IMG;
-    const __bf16* gl = gh + WW_IMG;
-    const __bf16* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
+    const hx_t* mi = img + (long)buf * 3 * WW_IMG;
+    const hx_t* gh = mi + WW_IMG;
+    const hx_t* gl = gh + WW_IMG;
+    const hx_t* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
     {
       // one v_mfma_f32_16x16x32_bf16 covers the whole 32-row group: its 8 k-values per lane are the two transposed reads of
       // rows 4 lq .. + 3 and 16 + 4 lq .. + 3 (the k order is free as long as A and B agree)
       auto cat = [](s16x4 x, s16x4 y) __attribute__((always_inline)) {
-        bf16x8 r;
+        hx8 r;
         *(s16x4*)&r = x; *((s16x4*)&r + 1) = y;
         return r;
       };
-      bf16x8 bh[2], bl[2];
+      hx8 bh[2], bl[2];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         bh[nb] = cat(ww_tr(gh, 0, ncol0 + 16 * nb, lane), ww_tr(gh, 16, ncol0 + 16 * nb, lane));
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       }
       const int dro0 = (4 * lq + (li >> 2)) * 16 + 4 * (li & 3), dro1 = dro0 + 16 * 16;
       typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-      bf16x8 bdh, bdl;
+      hx8 bdh, bdl;
       if (!TAILS) {
         bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
         bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
@@ -240,23 +245,23 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
       for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
         const int kb0 = 2 * kp, kb1 = kb0 + 1;
-        const bf16x8 a0 = cat(ww_tr(mi, 0, 16 * kb0, lane), ww_tr(mi, 16, 16 * kb0, lane));   // A[i = k][kk = m] = mask[m][k]
-        const bf16x8 a1 = cat(ww_tr(mi, 0, 16 * kb1, lane), ww_tr(mi, 16, 16 * kb1, lane));
+        const hx8 a0 = cat(ww_tr(mi, 0, 16 * kb0, lane), ww_tr(mi, 16, 16 * kb0, lane));   // A[i = k][kk = m] = mask[m][k]
+        const hx8 a1 = cat(ww_tr(mi, 0, 16 * kb1, lane), ww_tr(mi, 16, 16 * kb1, lane));
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bl[nb], acc[kb0][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bl[nb], acc[kb0][nb]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bl[nb], acc[kb1][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bl[nb], acc[kb1][nb]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bh[nb], acc[kb0][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bh[nb], acc[kb0][nb]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bh[nb], acc[kb1][nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bh[nb], acc[kb1][nb]);
         if (!TAILS && kp == 7) {                                     // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
-          const bf16x8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
-          const bf16x8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdl, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdl, accb[1], 0, 0, 0);
-          accb[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c0, bdh, accb[0], 0, 0, 0);
-          accb[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(c1, bdh, accb[1], 0, 0, 0);
+          const hx8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
+          const hx8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
+          accb[0] = ORL_MFMA_16x16x32(c0, bdl, accb[0]);
+          accb[1] = ORL_MFMA_16x16x32(c1, bdl, accb[1]);
+          accb[0] = ORL_MFMA_16x16x32(c0, bdh, accb[0]);
+          accb[1] = ORL_MFMA_16x16x32(c1, bdh, accb[1]);
         }
         // each staging register is written to LDS and refilled at the same point of every iteration: a full iteration in flight
         if (kp < 4) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
 
-  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0);
+  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
 }
 
 // ---- exact-fp32 flavour (precision 0): the same output-stationary structure on v_mfma_f32_16x16x4_f32 ----

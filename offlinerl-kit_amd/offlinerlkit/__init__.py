@@ -5,4 +5,4 @@ Mirrors the reference's API surface for that path only:
   offlinerlkit.policy_trainer.MFPolicyTrainer, offlinerlkit.nets / offlinerlkit.modules.
 All updates run in the HIP engine (liborlengine.so) through the C ABI in include/orl_engine.h.
 """
-__version__ = "0.1.0"
+__version__ = "0.5.0"      # = the engine version reported by orl_version()

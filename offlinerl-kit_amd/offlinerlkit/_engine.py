@@ -28,7 +28,7 @@ OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V, OPT_VAE = range(6
 
 # symbols include/orl_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "orl_last_error", "orl_version", "orl_config_default", "orl_arena_floats", "orl_engine_create",
+    "orl_last_error", "orl_version", "orl_split_bits", "orl_config_default", "orl_arena_floats", "orl_engine_create",
     "orl_engine_destroy", "orl_engine_sync", "orl_net_present", "orl_net_floats", "orl_net_num_tensors",
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
     "orl_set_lr", "orl_reset_optimizers", "orl_adam_get", "orl_adam_set", "orl_set_step_count", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
@@ -56,6 +56,7 @@ class OrlConfig(C.Structure):
         ("num_critics", C.c_int32), ("eta", C.c_float),
         ("cql_cons_row0", C.c_int32), ("cql_cons_rows", C.c_int32), ("cql_real_rows", C.c_int32),
         ("vae_hidden", C.c_int32), ("vae_latent", C.c_int32), ("mcq_lambda", C.c_float), ("behavior_lr", C.c_float),
+        ("ws_one_round", C.c_int32), ("ws_cus", C.c_int32),
         ("external_arena", C.c_void_p),
     ]
 
@@ -91,6 +92,7 @@ def load_library(path: Optional[str] = None):
     lib = C.CDLL(p)
     lib.orl_last_error.restype = C.c_char_p
     lib.orl_version.restype = C.c_char_p
+    lib.orl_split_bits.restype = C.c_int
     lib.orl_config_default.argtypes = [C.POINTER(OrlConfig), C.c_int32]
     lib.orl_config_default.restype = None
     lib.orl_arena_floats.argtypes = [C.POINTER(OrlConfig)]
@@ -145,6 +147,11 @@ def load_library(path: Optional[str] = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def split_bits() -> int:
+    """significand bits an operand carries at precision 1 (22: fp16 hi + lo planes; 16: the bf16-plane variant build)"""
+    return int(load_library().orl_split_bits())
 
 
 def last_error() -> str:

@@ -10,8 +10,11 @@ Bar, for EVERY element of every gradient tensor:  |g_hip - g_f64| <= C(precision
 absolute value, forward bounds included) -- the componentwise backward-error bound of arithmetic whose operands carry p significand
 bits and whose sums are accumulated in fp32:
     precision 0 (exact fp32 MFMA): C = 16 * 2^-24 (exact operands; what is bounded is the fp32 accumulation over up to 7936 rows and the
-    forward's rounding carried by the backward operands -- measured 0.40 / 0.46 of it)      precision 1 (split operands, hi + lo): C = 4 * 2^-17
-    (measured 0.05 / 0.19 of it)
+    forward's rounding carried by the backward operands -- measured 0.40 / 0.46 of it)
+    precision 1 (split operands, hi + lo planes of p = 22 bits [fp16 planes] or 16 bits [the bf16-plane variant build]): C = 16 * 2^-22 resp.
+    4 * 2^-17 (measured, fp16 planes: CQL h3 0.06, EDAC 0.36 of it; bf16 planes: 0.05 / 0.19) -- i.e. the fp16-plane engine's gradients sit
+    within 3x of the exact-fp32 engine's own backward error (EDAC, whose U(+-3e-3) tail weights put dq (x) w_tail near fp16's subnormal
+    range) and below it for the CQL critics
 A structural error (a dropped row group, a wrong operand pairing, a mis-indexed member) exceeds the bound by orders of magnitude;
 rounding cannot.  This replaces comparing a gradient with the fp32 numpy oracle at a widened bar: the oracle's own fp32 sums and
 its own ReLU decisions on pre-activations within an ulp of zero are not part of the statement here, because the float64 side is
@@ -28,7 +31,11 @@ from test_gpu_grads import _unpack_bits
 
 pytestmark = pytest.mark.gpu
 
-BOUND = {0: 16.0 * 2.0 ** -24, 1: 4.0 * 2.0 ** -17}
+def bound(precision):
+    if precision == 0:
+        return 16.0 * 2.0 ** -24
+    from offlinerlkit import _engine
+    return 16.0 * 2.0 ** -22 if _engine.split_bits() >= 22 else 4.0 * 2.0 ** -17
 
 
 def mlp_backward_f64(x, dq, Ws, bs, w_tail, masks):
@@ -109,7 +116,7 @@ def test_cql_three_layer_critic_backward_is_componentwise_backward_stable(precis
                 for l in range(L):
                     names[f"backbone.model.{2 * l}.weight"], names[f"backbone.model.{2 * l}.bias"] = f"W{l}", f"b{l}"
                 for pn, key in names.items():
-                    worst = max(worst, worst_ratio(got[pn], g[key], a[key], BOUND[precision], (precision, r, nm, pn)))
+                    worst = max(worst, worst_ratio(got[pn], g[key], a[key], bound(precision), (precision, r, nm, pn)))
         print(f"CQL h3 critic backward, precision {precision}: worst |err| / (C * abs-sum) = {worst:.3f}; mask flips vs float64: {flips}")
     finally:
         eng.close()
@@ -141,7 +148,7 @@ def test_edac_critic_backward_and_diversity_sweep_are_componentwise_backward_sta
     c = synth.EDAC_CASES[case]
     B, od, ad, hid, K = c["B"], c["obs_dim"], c["act_dim"], c["hidden"], cfg["num_critics"]
     L = len(hid)
-    C = BOUND[precision]
+    C = bound(precision)
     try:
         pre = ta._strip_saved({k: np.array(v, copy=True) for k, v in st["critics"].items()})
         b, n = batches[0], noises[0]

@@ -37,8 +37,23 @@ from helpers import clone_state
 
 pytestmark = pytest.mark.gpu
 
-# (max error / tensor scale, relative L2) bars per precision, step-0 gradients (same parameters on both sides)
-BARS = {0: (1e-4, 5e-5), 1: (5e-2, 1e-2)}
+# (max error / tensor scale, relative L2) bars per precision, step-0 gradients (same parameters on both sides).
+# Precision 1 with fp16 hi + lo planes (22 operand bits, round 3): measured worst tensors CQL [256,256] 2.5e-4 / 5.1e-5 (one ReLU on a
+# pre-activation within rounding distance of zero decided the other way than the oracle's BLAS: the exact-fp32 engine shows the same
+# kind of element at 2.5e-5), IQL 6.3e-7 / 6.4e-7, TD3+BC 6.7e-7 / 5.4e-7, EDAC 9.7e-7 / 5.2e-7 -- the bar is 50x tighter than the one the
+# bf16 planes of round 2 needed (5e-2 / 1e-2; kept for the bf16-plane variant build).
+BARS_SPLIT = {22: (1e-3, 2e-4), 16: (5e-2, 1e-2)}
+
+
+class _Bars(dict):
+    def __missing__(self, precision):
+        if precision == 0:
+            return (1e-4, 5e-5)
+        from offlinerlkit import _engine
+        return BARS_SPLIT[_engine.split_bits()]
+
+
+BARS = _Bars()
 
 
 def grad_err(got, ref):
@@ -107,6 +122,8 @@ def test_cql_critic_backward_is_componentwise_backward_stable(R):
     """bench.py's kernels (ws_fwd<TQ, L0, SY=false>, ws_dgrad_w0, ws_wgrad<2>: R = 96 -> 192 batched critics on 192 CUs, 128 -> 256)
     on the engine's own critic inputs, dq and packed masks vs float64: see the module docstring, check (1)."""
     from oracle import cql as ocql
+    from offlinerlkit import _engine
+    C = 16.0 * 2.0 ** -22 if _engine.split_bits() >= 22 else 4.0 * 2.0 ** -17      # fp16 planes (measured 0.22 of it) / bf16 planes (0.10)
     eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah", n_runs=R, precision=1)
     c = synth.CQL_CASES["cql_halfcheetah"]
     B, N, od, ad = c["B"], c["N"], c["obs_dim"], c["act_dim"]
@@ -132,11 +149,11 @@ def test_cql_critic_backward_is_componentwise_backward_stable(R):
                 got = eng.debug_grads(r, tc.NETS[nm])
                 for name in g:
                     err = np.abs(got[name].astype(np.float64).reshape(g[name].shape) - g[name])
-                    bound = 4.0 * 2.0 ** -17 * a[name] + 1e-30
+                    bound = C * a[name] + 1e-30
                     ratio = float((err / bound).max())
                     worst = max(worst, ratio)
                     assert ratio < 1.0, (R, r, nm, name, "componentwise backward error / bound", ratio)
-        print(f"CQL critic backward, R={R}: worst |err| / (4 * 2^-17 * abs-sum) = {worst:.3f}; mask flips vs float64: {flips_total}")
+        print(f"CQL critic backward, R={R}: worst |err| / ({C / 2.0 ** -22:.0f} * 2^-22 * abs-sum) = {worst:.3f}; mask flips vs float64: {flips_total}")
     finally:
         eng.close()
 
@@ -200,7 +217,12 @@ def test_cql_three_layer_gradients(precision):
     """reference CLI default [256,256,256] (run_cql.py:31): the middle layers go through the plain weight-stationary dgrad and the
     tiled wgrads; 32 runs, split-bf16 and exact fp32"""
     from oracle import cql as ocql
+    from offlinerlkit import _engine
     R = 32
+    # with fp16 hi + lo planes the split engine lands where the exact-fp32 engine does against the fp32 numpy oracle (measured relative L2
+    # 3.9e-4 on critic2's first layer in BOTH: one top-layer mask decided the other way than the oracle's BLAS); the sharp statement for
+    # this path is tests/test_gpu_backward_f64.py
+    fp32_like = precision == 0 or _engine.split_bits() >= 22
     eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=precision)
     init = clone_state({k: st[k] for k in ("actor", "critic1", "critic2")})
     try:
@@ -209,7 +231,7 @@ def test_cql_three_layer_gradients(precision):
             eng.step(tc.lead(b, R), tc.lead(tc.noise_list(n), R))
             for r in ((0, R - 1) if k == 0 else ()):
                 for nm in ("actor", "critic1", "critic2"):
-                    check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], ("h3", k, r, nm), precision, bars=BARS_FP32_3LAYER if precision == 0 else None)
+                    check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], ("h3", k, r, nm), precision, bars=BARS_FP32_3LAYER if fp32_like else None)
         check_params(eng, (0, R - 1), {nm: tc.NETS[nm] for nm in ("actor", "critic1", "critic2")}, st, 2, "cql_h3", init, rel_bar=0.15)     # measured 8.2 % (one top-layer mask flip reaches both layers below)
     finally:
         eng.close()

@@ -75,11 +75,17 @@ def _make(algo, case, R, precision):
 
 
 @pytest.mark.parametrize("algo,case,precision", [("cql", "cql_tiny", 0), ("cql", "cql_halfcheetah", 1), ("iql", "iql_hopper", 1),
-                                                 ("td3bc", "td3bc_halfcheetah", 1), ("edac", "edac_tiny", 0), ("edac", "edac_walker2d", 0)])
+                                                 ("td3bc", "td3bc_halfcheetah", 1), ("edac", "edac_tiny", 0), ("edac", "edac_walker2d", 0),
+                                                 ("edac", "edac_walker2d", 1)])
 def test_learn_n_graph_replay_matches_oracle_and_eager_step(algo, case, precision):
-    """(EDAC's full-size case runs in exact fp32 here: its gradient-diversity loss is piecewise constant in the ReLU masks, and on
-    device-drawn batches the split-bf16 engine's second step landed 1.2e-4 from the oracle -- outside the gate the fixture batches
-    meet in test_gpu_algos.py; this test is about the sampling / graph path, not the multiply.)"""
+    """(EDAC's full-size case in split precision is the round-2 miss: with bf16 hi + lo planes its second step on device-drawn batches
+    landed 1.2e-4 from the oracle -- the gradient-diversity loss is piecewise constant in the ReLU masks, and 16-bit operands moved the
+    first step's parameters far enough to flip some.  With fp16 hi + lo planes (22 bits) it is inside the gate; the bf16-plane variant
+    build is skipped for that case.)"""
+    if (algo, case, precision) == ("edac", "edac_walker2d", 1):
+        from offlinerlkit import _engine
+        if _engine.split_bits() < 22:
+            pytest.skip("bf16-plane variant build: EDAC on device-drawn batches is 1.2e-4 from the oracle at 16 operand bits")
     R, steps = 3, 4
     eng, mod, cfg, st, c = _make(algo, case, R, precision)
     eager, _, _, _, _ = _make(algo, case, R, precision)
