@@ -32,18 +32,31 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "offlinerl-kit_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+for p in (ROOT, os.path.join(ROOT, "offlinerl-kit_amd")):       # (the checker's paths -- tests/, oracle/ -- are added by cpu_baseline() only)
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import bench_workloads as bw
+
 OBS, ACT, HIDDEN, BATCH, NREP = 17, 6, [256, 256], 256, 10
-# MI355X_MICROARCH.md: fp32 MFMA dense peak 157.3 TFLOP/s; bf16 MFMA dense peak ~2500 TFLOP/s.  precision=1 spends three
-# bf16 MFMAs per fp32-equivalent product, so its ceiling for ALGORITHMIC flops is 2500/3.
+TARGET_STEPS_PER_S = 50_000.0       # BASELINE.json north_star: >= 50k CQL gradient-steps/s on one MI355X
+# MI355X_MICROARCH.md: fp32 MFMA dense peak 157.3 TFLOP/s; bf16 / fp16 MFMA dense peak ~2500 TFLOP/s.  precision=1 spends three
+# 16-bit MFMAs per fp32-equivalent product, so its ceiling for ALGORITHMIC flops is 2500/3.
 PEAK_TFLOPS = {0: 157.3, 1: 2500.0 / 3.0}
-DTYPE = {0: "f32 (v_mfma_f32_16x16x4_f32: the reference's arithmetic)",
-         1: "f32 storage / accumulate; products on split-bf16 MFMA (operands = bf16 hi + bf16 lo = 16 significand bits, hi*hi + hi*lo + lo*hi "
-            "on v_mfma_f32_16x16x32_bf16): losses and Q-values meet the 1e-4 parity gate in this mode (tests/test_gpu_cql.py), gradients are "
-            "componentwise backward-stable at 2^-17 (tests/test_gpu_grads.py); the exact-fp32 figure of the same run is in `fp32`"}
+
+
+def dtype_string(precision):
+    if precision == 0:
+        return "f32 (v_mfma_f32_16x16x4_f32: the reference's arithmetic)"
+    from offlinerlkit import _engine
+    if _engine.split_bits() >= 22:
+        return ("f32 storage / accumulate; products on split-fp16 MFMA (every operand = fp16 hi + fp16 lo plane = 22 significand bits, power-of-two "
+                "operand scales folded back into the fp32 accumulators, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; the reference's fp32 has 24): "
+                "losses and Q-values meet the 1e-4 parity gate (tests/test_gpu_cql.py), gradients agree with the fp32 oracle to 1e-6 .. 2.5e-4 of the "
+                "tensor scale and are componentwise backward-stable at 2^-20 (tests/test_gpu_grads.py, test_gpu_backward_f64.py); the exact-fp32 "
+                "figure of the same run is `value_fp32` / `fp32`")
+    return ("f32 storage / accumulate; products on split-bf16 MFMA (bf16-plane variant build: operands = bf16 hi + bf16 lo = 16 significand bits); "
+            "the exact-fp32 figure of the same run is `value_fp32` / `fp32`")
 PRESETS = {
     # BASELINE config 5: 8 seeds x 8 tasks, one task (its own synthetic buffer) and its 8 seeds per GPU, one engine
     "config5": dict(runs_per_gpu=8, engines_per_gpu=1),
@@ -101,39 +114,16 @@ def cql_algorithmic_flops(B=BATCH, N=NREP, od=OBS, ad=ACT, hidden=HIDDEN):
 
 
 def make_dataset(seed, n=1_000_000, od=OBS, ad=ACT):
-    rng = np.random.RandomState(seed)
-    return dict(
-        obs=rng.standard_normal((n, od)).astype(np.float32),
-        act=np.tanh(rng.standard_normal((n, ad))).astype(np.float32),
-        nobs=rng.standard_normal((n, od)).astype(np.float32),
-        rew=rng.standard_normal(n).astype(np.float32),
-        term=(rng.uniform(size=n) < 0.01).astype(np.float32),
-    )
+    return bw.make_dataset(seed, n, od, ad)
 
 
-def init_weights(eng, run, seed):
-    import synth
-    rng = np.random.RandomState(1000 + seed)
-    actor = synth.make_tanh_actor(rng, OBS, ACT, HIDDEN)
-    c1 = synth.make_critic(rng, OBS + ACT, HIDDEN)
-    c2 = synth.make_critic(rng, OBS + ACT, HIDDEN)
-    eng.set_net(run, 0, actor)
-    eng.set_net(run, 1, c1); eng.set_net(run, 2, c2)
-    eng.set_net(run, 3, c1); eng.set_net(run, 4, c2)      # deepcopy targets (sac.py:29-33)
-    return dict(actor=actor, critic1=c1, critic2=c2)
-
-
-def make_cql_engines(E, R, device, precision, seed0, buf):
-    from offlinerlkit import _engine
+def make_cql_engines(E, R, device, precision, seed0, buf, one_round=None):
+    """E engines x R runs of the headline workload on one GPU.  With several engines per GPU each engine's weight-stationary launches stay on
+    CUs / nets workgroups per net (one round): the CUs they leave idle are where the other engine's kernels run (orl_config::ws_one_round)."""
     engines = []
     for e in range(E):
-        cfg = _engine.default_config("cql", obs_dim=OBS, act_dim=ACT, hidden=HIDDEN, batch_size=BATCH, n_runs=R, device=device,
-                                     precision=precision, seed=1234 + 7919 * (seed0 * E + e), num_repeat_actions=NREP,
-                                     target_entropy=-float(ACT))
-        g = _engine.Engine(cfg)
+        g = bw.make_engine("cql", R, precision, device, seed0 * E + e, ws_one_round=(E > 1) if one_round is None else one_round)
         g.attach_buffer(buf)                              # all engines of a GPU sample the same HBM-resident dataset
-        for r in range(R):
-            init_weights(g, r, (seed0 * E + e) * R + r)
         engines.append(g)
     return engines
 
@@ -174,7 +164,14 @@ def timed_rate(engines, steps, min_seconds, min_reps=1, max_reps=40):
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baselines (rank 0, N = 1): the torch-CPU counterpart at all cores and at 1 thread, and the numpy oracle
 # ---------------------------------------------------------------------------------------------------------------
+def _checker_paths():
+    for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
 def _cql_cpu_state():
+    _checker_paths()
     import synth
     from helpers import clone_state
     rng = np.random.RandomState(5)
@@ -190,6 +187,7 @@ def cpu_baseline(seconds=24.0):
     """the build's PyTorch-CPU counterpart of CQLPolicy.learn (oracle/torch_cql.py, pinned against the
     reference fixtures in tests/test_oracle_golden.py) on this box's host cores -- all cores available to the process and one
     thread -- plus the numpy oracle; same synthetic workload, a bounded sample of steps each."""
+    _checker_paths()
     import synth
     import torch
     from oracle import cql as ocql
@@ -245,19 +243,19 @@ def cpu_baseline(seconds=24.0):
 
 
 def pmc_traffic(tag, runs, precision):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
-    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction; profiles/pmc_traffic.json).
-    PMC counters cannot be collected from inside the timed process, so the figure is only reported when the committed
-    measurement was taken on the same kernel tag, run count and precision; otherwise null."""
+    """(bytes per launch, source) of the dominant kernel from the COMMITTED PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 FETCH_SIZE x2 correction; profiles/pmc_traffic.json).  PMC counters cannot be collected from inside
+    the timed process, so this is not a measurement of THIS run: it is reported (with its source) only when the committed passes were taken
+    on the same kernel tag, run count and precision; otherwise null."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         e = t.get(tag)
         if e and e["runs_per_gpu"] == runs and e["precision"] == precision:
-            return e["bytes_per_launch"]
+            return e["bytes_per_launch"], "profiles/pmc_traffic.json (%s; taken at %s)" % (e.get("source", "rocprofv3 --pmc"), e.get("commit", "an earlier commit"))
     except Exception:
         pass
-    return None
+    return None, None
 
 
 def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump=""):
@@ -285,8 +283,10 @@ def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump
     ach = top["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
     gbps = top["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic(top["name"], R, precision)
     roof = dict(bound="mfma", kernel=top["name"], achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
-                traffic=pmc_traffic(top["name"], R, precision), avg_launch_ms=avg_ms, flops_per_launch=top["flops_per_launch"],
+                traffic=traffic, traffic_source=traffic_source, avg_launch_ms=avg_ms, avg_launch_from="eager launches of engine 0 alone, HIP events on its stream",
+                flops_per_launch=top["flops_per_launch"],
                 # the same launch against the HBM roof (algorithmic bytes: operands read once, result written once)
                 hbm=dict(bytes_per_launch=top["bytes_per_launch"], achieved=gbps, peak=8000.0, unit="GB/s", frac=gbps / 8000.0),
                 table=[dict(name=t["name"], ms_per_step=t["total_ms"] / steps, launches_per_step=t["launches"] / steps) for t in table[:12]])
@@ -296,18 +296,16 @@ def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump
 
 
 def other_config(algo, device, precision, R, seconds):
-    """BASELINE configs 3 / 4 through the same engine: IQL hopper-medium-replay shape, EDAC walker2d-medium-expert shape
-    (the full-size parity cases' shapes and hyper-parameters, synthetic buffers of the D4RL sizes)."""
-    import synth
-    import test_gpu_algos as ta
+    """BASELINE configs 1 / 3 / 4 through the same engine: TD3+BC halfcheetah shape, IQL hopper-medium-replay shape, EDAC walker2d-medium-expert
+    shape (bench_workloads.py: the launch scripts' hyper-parameters and initialisation, synthetic buffers of the D4RL sizes)."""
     from offlinerlkit import _engine
-    case = {"iql": "iql_hopper", "edac": "edac_walker2d"}[algo]
-    c = getattr(synth, f"{algo.upper()}_CASES")[case]
-    n = {"iql": 400_000, "edac": 2_000_000}[algo]
-    eng, mod, cfg, st, _, _ = ta.make_engine(algo, case, n_runs=R, precision=precision)
-    ds = make_dataset(3, n, c["obs_dim"], c["act_dim"])
-    buf = _engine.DeviceBuffer(c["obs_dim"], c["act_dim"], device)
+    w = bw.WORKLOADS[algo]
+    eng = bw.make_engine(algo, R, precision, device, 11)
+    ds = make_dataset(3, w["n"], w["obs"], w["act"])
+    buf = _engine.DeviceBuffer(w["obs"], w["act"], device)
     buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+    if algo == "td3bc":
+        buf.normalize_obs(1e-3)                           # run_td3bc.py:71
     eng.attach_buffer(buf)
     eng.learn_n(30)
     steps = 100
@@ -316,12 +314,111 @@ def other_config(algo, device, precision, R, seconds):
     roof = profile_roofline(eng, 10, precision, R)
     if roof:
         roof.pop("table", None)
-    out = dict(workload=f"{algo.upper()} {case} shape: obs{c['obs_dim']}/act{c['act_dim']}, batch {c['B']}, hidden {c['hidden']}"
-                        + (f", {cfg['num_critics']} critics, eta {cfg['eta']}" if algo == "edac" else f", expectile {cfg['expectile']}")
-                        + f", {n} synthetic transitions, 1 engine x {R} runs, device sampling",
-               value=R * steps / dt, unit="gradient-steps/s", ms_per_step=dt / steps * 1e3, precision=precision, roofline=roof)
+    value = R * steps / dt
+    out = dict(workload=bw.workload_string(algo, R), value=value, unit="gradient-steps/s", ms_per_step=dt / steps * 1e3, precision=precision,
+               algorithmic_gflop_per_gradient_step=w["gflop"],
+               step_frac_of_mlp_gemm_roofline=value * w["gflop"] * 1e9 / (PEAK_TFLOPS[precision] * 1e12), roofline=roof)
     eng.close(); buf.close()
     return out
+
+
+def api_record(device, precision, R, steps, dataset):
+    """The same workload through the reference-shaped Python API: CQLPolicy built from torch modules as run_cql.py:80-128 does,
+    ``set_engine_options(n_runs, precision)``, ``ReplayBuffer.load_dataset``, one fused ``MFPolicyTrainer`` epoch (sample -> learn x steps on
+    the device, one readback; evaluation excluded).  The first epoch pays binding + graph capture and is not timed."""
+    import tempfile
+    import torch
+    from offlinerlkit.buffer import ReplayBuffer
+    from offlinerlkit.modules import ActorProb, Critic, TanhDiagGaussian
+    from offlinerlkit.nets import MLP
+    from offlinerlkit.policy import CQLPolicy
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+    from offlinerlkit.utils.logger import Logger
+
+    class Space:
+        low, high, shape = np.full(ACT, -1.0, np.float32), np.full(ACT, 1.0, np.float32), (ACT,)
+    dev = f"cuda:{device}"
+    torch.manual_seed(0)
+    actor = ActorProb(MLP(OBS, HIDDEN), TanhDiagGaussian(HIDDEN[-1], ACT, unbounded=True, conditioned_sigma=True), dev)
+    c1, c2 = Critic(MLP(OBS + ACT, HIDDEN), dev), Critic(MLP(OBS + ACT, HIDDEN), dev)
+    log_alpha = torch.zeros(1, requires_grad=True, device=dev)
+    pol = CQLPolicy(actor, c1, c2, torch.optim.Adam(actor.parameters(), lr=1e-4), torch.optim.Adam(c1.parameters(), lr=3e-4),
+                    torch.optim.Adam(c2.parameters(), lr=3e-4), action_space=Space(), tau=0.005, gamma=0.99,
+                    alpha=(-float(ACT), log_alpha, torch.optim.Adam([log_alpha], lr=1e-4)), cql_weight=5.0, temperature=1.0,
+                    max_q_backup=False, deterministic_backup=True, with_lagrange=False, lagrange_threshold=10.0, cql_alpha_lr=3e-4,
+                    num_repeart_actions=NREP)
+    pol.set_engine_options(n_runs=R, precision=precision, seed=5)
+    n = len(dataset["rew"])
+    buf = ReplayBuffer(n, (OBS,), np.float32, ACT, np.float32, device=dev)
+    buf.load_dataset(dict(observations=dataset["obs"], actions=dataset["act"], next_observations=dataset["nobs"],
+                          rewards=dataset["rew"], terminals=dataset["term"]))
+    with tempfile.TemporaryDirectory() as tmp:
+        logger = Logger(tmp, {"policy_training_progress": "csv"})
+        tr = MFPolicyTrainer(pol, None, buf, logger, epoch=1, step_per_epoch=steps, batch_size=BATCH, eval_episodes=0)
+        tr._train_epoch(1)                               # binding, buffer upload, graph capture
+        torch.cuda.synchronize()
+        times = []
+        for e in (2, 3, 4):
+            t0 = time.perf_counter()
+            tr._train_epoch(e)                           # policy.learn_n(steps) + logger.logkv of the epoch means
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        logger.close()
+    dt = float(np.median(times))
+    finite = bool(np.isfinite([v for v in getattr(logger, "_name2val", {}).values() if isinstance(v, (int, float))]).all())
+    if pol.engine is not None:
+        pol.engine.close()
+    return dict(what="MFPolicyTrainer fused epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer (reference constructor signatures), "
+                     "%d steps per epoch, n_runs=%d, precision=%d, one engine, evaluation excluded" % (steps, R, precision),
+                value=R * steps / dt, unit="gradient-steps/s", epoch_seconds=times, finite=finite)
+
+
+def rccl_check(local_rank):
+    """World-size-1 rehearsal of the ONLY collective of the path on the one GPU a builder box has: the `nccl` (= RCCL) process group is
+    created exactly as the N > 1 branch of main() creates it (device_id = this rank's GPU), a few engine steps run, and the three collective
+    calls of the path execute on device tensors -- all_reduce(MAX) of the block time, all_gather of the per-run metric table (here and through
+    MFPolicyTrainer._gather), barrier -- before the group is destroyed.  Prints one line `RCCL {json}`.  Proves that RCCL loads, binds the
+    device and moves the metric table; it is not a scaling measurement."""
+    import torch
+    import torch.distributed as dist
+    from offlinerlkit import _engine
+    from offlinerlkit.policy_trainer import MFPolicyTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), rank=0, world_size=1)
+    ds = make_dataset(0, 50_000)
+    buf = _engine.DeviceBuffer(OBS, ACT, local_rank)
+    buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+    engines = make_cql_engines(1, 8, local_rank, 1, 0, buf)
+    t0 = time.perf_counter()
+    res = learn_all(engines, 5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt, 1.0], device="cuda", dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    metrics = res[0][0]
+    mine = torch.tensor(metrics, device="cuda", dtype=torch.float32)
+    allm = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allm, mine)
+    gathered = torch.stack(allm).cpu().numpy()
+
+    class _Log:
+        def __init__(self): self.kv = {}
+        def logkv(self, k, v): self.kv[k] = v
+    tr = MFPolicyTrainer(None, None, None, _Log(), fused=False)
+    tr._gather({"loss/critic1": float(metrics[0, 1]), "loss/actor": float(metrics[0, 0])})
+    dist.barrier()
+    out = dict(backend=dist.get_backend(), world=dist.get_world_size(), all_reduce_max_ok=bool(abs(float(t[0].item()) - dt) < 1e-9),
+               all_gather_shape=list(gathered.shape), all_gather_equal=bool(np.array_equal(gathered[0], metrics)),
+               finite=bool(np.isfinite(gathered).all()), trainer_gathered=sorted(tr.gathered_metrics[0].keys()) if tr.gathered_metrics else None,
+               trainer_logged=sorted(tr.logger.kv.keys()), nccl_version=list(torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None)
+    dist.destroy_process_group()
+    for g in engines:
+        g.close()
+    buf.close()
+    os.write(1, ("RCCL " + json.dumps(out) + "\n").encode())
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -345,6 +442,7 @@ def main():
     ap.add_argument("--profile-dump", default="", help="write the full per-launch-tag timing table (HIP events) to this file")
     ap.add_argument("--dataset-size", type=int, default=1_000_000)
     ap.add_argument("--launch-check", action="store_true", help="print this rank's RANK / LOCAL_RANK / WORLD_SIZE as JSON and exit (no GPU use)")
+    ap.add_argument("--rccl-check", action="store_true", help="world-size-1 `nccl` process group on this GPU: the path's collectives on device tensors, then exit")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -360,14 +458,12 @@ def main():
         sys.stdout.flush()
         os.write(1, ("LAUNCH " + json.dumps(dict(rank=rank, local_rank=local_rank, world=world, gpus=args.gpus)) + "\n").encode())
         return
+    if args.rccl_check:
+        return rccl_check(local_rank)
     preset = PRESETS.get(args.preset, {})
     R = args.runs_per_gpu if args.runs_per_gpu is not None else int(os.environ.get("ORL_RUNS_PER_GPU", preset.get("runs_per_gpu", 96)))
     E = max(1, args.engines_per_gpu if args.engines_per_gpu is not None else int(os.environ.get("ORL_ENGINES_PER_GPU", preset.get("engines_per_gpu", 2))))
 
-    if E > 1:
-        # several engines per GPU: each engine's weight-stationary launches stay on CUs / nets workgroups per net (one round), the CUs
-        # they leave idle are where the other engine's kernels run (csrc/ws_gemm.h: ws_blocks_per_problem)
-        os.environ.setdefault("ORL_WS_ONE_ROUND", "1")
     import torch
     dist = None
     backend = os.environ.get("ORL_DIST_BACKEND", "nccl")      # "gloo" only to rehearse the N>1 path on one GPU
@@ -426,6 +522,10 @@ def main():
     else:
         metrics_all = metrics[None]
     assert np.isfinite(metrics_all).all(), "non-finite losses"
+    for g in engines:                                  # (the integer-view ReLU can scrub NaNs out of the forward: look at the parameters too)
+        for r in (0, R - 1):
+            for net in (0, 1, 2):
+                assert all(np.isfinite(v).all() for v in g.get_net(r, net).values()), "non-finite parameters after the timed steps"
 
     total_steps = args.steps * R * E * world
     dt_med = float(np.median(reps))
@@ -437,8 +537,9 @@ def main():
             roof = profile_roofline(eng, args.profile_steps, args.precision, R, flops_step, value / world, args.profile_dump)
             if roof and roof["kernel"].startswith("critic."):
                 # one weight-stationary workgroup owns a CU; with several engines per GPU a launch stays on 2 * runs workgroups (one round,
-                # ORL_WS_ONE_ROUND) and the other engines' kernels run on the CUs it leaves idle: `frac` is against the whole chip
-                cus = min(256, 2 * R) if os.environ.get("ORL_WS_ONE_ROUND") == "1" else 256
+                # orl_config::ws_one_round) and the other engines' kernels run on the CUs it leaves idle: `frac` is against the whole chip
+                one_round = (E > 1) if os.environ.get("ORL_WS_ONE_ROUND") is None else os.environ["ORL_WS_ONE_ROUND"] == "1"
+                cus = min(256, 2 * R) if one_round else 256
                 roof["cus_occupied_by_the_launch"] = cus
                 roof["frac_of_occupied_cus"] = roof["frac"] * 256.0 / cus
         for g in engines:
@@ -446,9 +547,9 @@ def main():
         engines = []
         sides = world == 1 and not args.no_sides
         by_runs, fp32, others = None, None, None
+        api = None
         if sides:
-            os.environ["ORL_WS_ONE_ROUND"] = "0"          # the side engines run alone on the GPU: whole rounds of workgroups
-            by_runs = []
+            by_runs = []                                 # (single side engines run alone on the GPU: whole rounds of workgroups)
             for r_side in (1, 8, 32, 96):
                 es = make_cql_engines(1, r_side, local_rank, args.precision, 100 + r_side, buf)
                 learn_all(es, 30)
@@ -459,8 +560,6 @@ def main():
                 es[0].close()
             by_runs.append(dict(runs_per_gpu=R * E, engines_per_gpu=E, value=value, ms_per_step=dt_med / args.steps * 1e3))
             if args.precision != 0:
-                if E > 1:
-                    os.environ["ORL_WS_ONE_ROUND"] = "1"
                 es = make_cql_engines(E, R, local_rank, 0, 7, buf)
                 learn_all(es, 10)
                 n32 = 20
@@ -469,18 +568,23 @@ def main():
                 r32 = profile_roofline(es[0], 5, 0, R)
                 if r32:
                     r32.pop("table", None)
-                fp32 = dict(value=R * E * n32 / d, unit="gradient-steps/s", ms_per_step=d / n32 * 1e3, dtype=DTYPE[0], steps_per_block=n32,
+                fp32 = dict(value=R * E * n32 / d, unit="gradient-steps/s", ms_per_step=d / n32 * 1e3, dtype=dtype_string(0), steps_per_block=n32,
                             reps_s=rr, seconds_timed=float(np.sum(rr)), engines_per_gpu=E, runs_per_engine=R, roofline=r32)
                 for g in es:
                     g.close()
-            os.environ["ORL_WS_ONE_ROUND"] = "0"
-            others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("iql", "edac")}
+            others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac")}
+            api = api_record(local_rank, args.precision, 128, 1000, ds)
         cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {
             "metric": "gradient-steps/sec (CQL, batch=256)", "value": value, "unit": "gradient-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_med / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE[args.precision],
+            "dtype": dtype_string(args.precision),
+            # the same workload in the reference's own arithmetic (exact fp32 MFMA), measured in this run, next to the headline
+            "value_fp32": (value if args.precision == 0 else (fp32["value"] if fp32 else None)),
+            "target": {"steps_per_s": TARGET_STEPS_PER_S, "value_over_target": value / world / TARGET_STEPS_PER_S,
+                       "value_fp32_over_target": ((value / world if args.precision == 0 else fp32["value"]) / TARGET_STEPS_PER_S) if (fp32 or args.precision == 0) else None,
+                       "note": "BASELINE.json north_star target, per GPU; published reference numbers: none (vs_baseline null)"},
             "data": "synthetic D4RL-shaped replay buffer (N(0,1) obs, tanh actions), random-init weights",
             "config": {"workload": "CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
                                    "auto-alpha, device sampling+noise, %d engine(s) x %d run(s) per GPU x %d GPU(s) (independent seeds; value = steps of all runs)" % (E, R, world),
@@ -490,7 +594,7 @@ def main():
                        "dist_backend": backend if world > 1 else None},
             "reps": {"blocks": len(reps), "steps_per_block": args.steps, "block_seconds": reps, "value_is": "median block",
                      "value_min": total_steps / max(reps), "value_max": total_steps / min(reps), "seconds_timed": float(np.sum(reps))},
-            "roofline": roof, "cpu_baseline": cpu, "fp32": fp32, "by_runs": by_runs, "other_configs": others,
+            "roofline": roof, "cpu_baseline": cpu, "fp32": fp32, "by_runs": by_runs, "other_configs": others, "api": api,
             "single_run": by_runs[0] if by_runs else None,
             "metrics_gathered": {"shape": list(metrics_all.shape), "loss_critic1_mean_per_rank": [float(x) for x in metrics_all[:, :, 1].mean(axis=1)]},
             "final_metrics_rank0_run0": dict(zip(eng.metric_names, [float(x) for x in metrics[0]])),

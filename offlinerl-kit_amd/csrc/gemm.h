@@ -94,6 +94,10 @@ __device__ __forceinline__ void orl_split1(float x, hx_t& h, hx_t& l) { h = (hx_
 // integers), min(bits, 1u) of the result is the mask bit.  v_max_i32 / v_min_u32 are full-rate vector instructions (2.5 cycles of a
 // gfx950 SIMD against 4.4 for v_max_f32 and for the compare + select pairs the float formulation compiles to; nothing overlaps with
 // the MFMAs: DESIGN.md §5).
+// NaN: torch.relu propagates a NaN; here a NaN whose sign bit is set is a negative integer and becomes +0 (mask bit 0), one with a clear
+// sign bit stays a NaN.  A diverged run can therefore have part of its NaNs scrubbed inside the forward instead of surfacing in the losses:
+// training health checks must look at the parameters (Adam writes the NaN gradient of the first non-finite step into them), not only at
+// the metrics -- tests/test_gpu_training.py does, and bench.py asserts finite metrics AND finite sampled parameters.
 __device__ __forceinline__ unsigned int orl_relu_mask4(f32x4& z) {
   unsigned int m = 0;
 #pragma unroll

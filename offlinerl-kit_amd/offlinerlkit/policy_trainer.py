@@ -69,7 +69,7 @@ class MFPolicyTrainer:
     def _gather(self, kv: Dict[str, float]) -> None:
         """End-of-epoch metric all-gather: every rank contributes its metric vector, rank 0 logs ``rank<i>/<key>``."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         keys = sorted(kv)
         backend = dist.get_backend()

@@ -15,7 +15,7 @@ from typing import Dict, Optional
 import numpy as np
 
 
-def _keep_mask(dataset: Dict[str, np.ndarray], terminate_on_end: bool, max_episode_steps: Optional[int]) -> np.ndarray:
+def _keep_mask(dataset: Dict[str, np.ndarray], terminate_on_end: bool, max_episode_steps: Optional[int], with_last: bool = False):
     """Which of the first N-1 rows survive (load_dataset.py:64-112).
 
     A row is the LAST of its trajectory when ``timeouts`` says so (or, without that field, when the running count of kept rows of
@@ -42,32 +42,52 @@ def _keep_mask(dataset: Dict[str, np.ndarray], terminate_on_end: bool, max_episo
                 step = 1 if has_next else 0
             else:
                 step += 1
-    if terminate_on_end:
-        return ~((done | last) & (not has_next))
-    return ~last & ~(done & (not has_next))
+    keep = ~((done | last) & (not has_next)) if terminate_on_end else ~last & ~(done & (not has_next))
+    return (keep, last) if with_last else keep
+
+
+def _rtgs(dataset: Dict[str, np.ndarray], keep: np.ndarray, last: np.ndarray, terminate_on_end: bool) -> np.ndarray:
+    """``rtgs`` of ``get_rtg=True`` exactly as the reference computes them (load_dataset.py:54-55, 87-93, 101-105, 114-125), including what
+    it does NOT do: ``acc_ret_traj_`` is never cleared, so at every trajectory end the return-to-go of EVERY row kept so far is appended
+    again, and rows after the last trajectory end are never flushed -- the reference's own assertion (:130) then fails.  It holds for one
+    case only: a single trajectory whose end is the last row the loop visits.  That case is returned (float32, accumulated in row order
+    like the reference's ``ret += reward``); every other dataset raises the reference's AssertionError."""
+    n = keep.shape[0]
+    done = np.asarray(dataset["terminals"][:n]).astype(bool)
+    has_next = "next_observations" in dataset
+    # rows at which the reference flushes acc_ret_traj_ into rtg_: a skipped trajectory end (:84-95, :98-107) or a kept one (:119-125)
+    flush = (last & (not terminate_on_end)) | ((done | last) & ((not has_next) | keep))
+    kept_before = np.cumsum(keep) - keep                       # rows kept strictly before row i
+    n_rtg = int((kept_before + keep)[flush].sum())             # a flush appends one entry per row kept so far (this row included if kept)
+    n_obs = int(keep.sum())
+    assert n_obs == n_rtg, f"Obs {n_obs} and Rtg {n_rtg} should be same length!"
+    r = np.asarray(dataset["rewards"])[:n][keep].astype(np.float32)
+    acc = np.cumsum(r, dtype=np.float32)                       # ret after each kept row, float32 like `ret += reward`
+    before = np.concatenate([np.zeros(1, np.float32), acc[:-1]]) if len(acc) else acc
+    return (acc[-1] - before).astype(np.float32) if len(acc) else np.zeros(0, np.float32)
 
 
 def qlearning_dataset(env=None, dataset: Optional[Dict[str, np.ndarray]] = None, terminate_on_end: bool = False,
                       get_rtg: bool = False, **kwargs) -> Dict[str, np.ndarray]:
     """observations / actions / next_observations / rewards / terminals of every usable transition (load_dataset.py:17-147).
     ``next_observations`` are the dataset's own when present, otherwise the following row's observation."""
-    if get_rtg:
-        raise NotImplementedError("get_rtg=True (return-to-go for the RCSL policies) is outside this build's scope; the reference's own "
-                                  "implementation asserts at load_dataset.py:130 on datasets with more than one trajectory")
     if dataset is None:
         dataset = env.get_dataset(**kwargs)
     n = dataset["rewards"].shape[0] - 1
-    keep = _keep_mask(dataset, terminate_on_end, getattr(env, "_max_episode_steps", None))
+    keep, last = _keep_mask(dataset, terminate_on_end, getattr(env, "_max_episode_steps", None), with_last=True)
     idx = np.nonzero(keep)[0]
     obs = np.asarray(dataset["observations"])
     nxt = np.asarray(dataset["next_observations"])[idx] if "next_observations" in dataset else obs[idx + 1]
-    return {
+    out = {
         "observations": obs[idx].astype(np.float32),
         "actions": np.asarray(dataset["actions"])[idx].astype(np.float32),
         "next_observations": nxt.astype(np.float32),
         "rewards": np.asarray(dataset["rewards"])[idx].astype(np.float32),
         "terminals": np.asarray(dataset["terminals"][:n]).astype(bool)[idx],
     }
+    if get_rtg:                                                # key 'rtgs' (load_dataset.py:139-147); see _rtgs for what the reference accepts
+        out["rtgs"] = _rtgs(dataset, keep, last, terminate_on_end)
+    return out
 
 
 def normalize_rewards(dataset: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:

