@@ -162,6 +162,9 @@ struct Engine {
   int gscale_next = 0;
   const float* cur_gscale = nullptr; // scale array [R] of the current backward pass (null: precision 0 or outside a backward pass)
   const float* grad_scale(const Mat& seed, int rows, int cols, int nets, const char* tag);
+  float* gscale_slot();              // next slot for a seed kernel that publishes the scale itself (GradScaleP-free path); null at precision 0
+  float* gscale_inv_b = nullptr;     // [R] constant scale of seeds whose entries are +-1/B (actor-loss dq)
+  unsigned int* cql_ticket = nullptr;  // [R] arrival counters of k_cql_loss_rows
 
   ~Engine();
   int init(const orl_config& c);

@@ -277,6 +277,12 @@ void Engine::prof_end() {
   hipEventRecord(prof.back().b, stream);
 }
 
+float* Engine::gscale_slot() {
+  if (cfg.precision != 1) return nullptr;
+  if (gscale_next >= GSCALE_SLOTS) { fail("grad_scale: out of slots"); return nullptr; }
+  return gscale_buf + (long)(gscale_next++) * R;
+}
+
 // split precision: choose the dynamic scale of a backward pass from its seed (kernels.h: k_grad_scale); null at precision 0
 const float* Engine::grad_scale(const Mat& seed, int rows, int cols, int nets, const char* tag) {
   if (cfg.precision != 1) return nullptr;
@@ -879,7 +885,15 @@ int Engine::init(const orl_config& c) {
   hyper = (Hyper*)raw_alloc(sizeof(Hyper));
   gstep = (unsigned long long*)raw_alloc(sizeof(unsigned long long));
   gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
-  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf) return fail("hipMalloc state");
+  gscale_inv_b = raw_alloc(sizeof(float) * (size_t)R);
+  cql_ticket = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
+  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket) return fail("hipMalloc state");
+  {
+    std::vector<float> inv(R, orl_pow2_scale(1.0f / (float)c.batch_size));
+    ORL_HIP(hipMemcpyAsync(gscale_inv_b, inv.data(), sizeof(float) * R, hipMemcpyHostToDevice, stream));
+    ORL_HIP(hipMemsetAsync(cql_ticket, 0, sizeof(unsigned int) * R, stream));
+    ORL_HIP(hipStreamSynchronize(stream));
+  }
   memset(&hyper_host, 0, sizeof(hyper_host));
   hyper_host.lr[ORL_OPT_ACTOR] = c.actor_lr;
   hyper_host.lr[ORL_OPT_CRITIC] = c.critic_lr;
@@ -989,9 +1003,9 @@ int Engine::enqueue_prepare(bool sampling, bool devnoise) {
     if (!buf || !buf->obs) return fail("no replay buffer attached (orl_engine_attach_buffer)");
     p.d_obs = buf->obs; p.d_nobs = buf->nobs; p.d_act = buf->act; p.d_rew = buf->rew; p.d_term = buf->term; p.n = buf->n;
     p.OP = buf->OP; p.AP = buf->AP;
-    p.idx = d_idx; p.idx_rs = B;
-    ORL_LAUNCH("draw_indices", k_draw_indices, dim3((B + 255) / 256, R), dim3(256), d_idx, (long)B, B, (long)buf->n, (unsigned long long)cfg.seed,
-               (const unsigned long long*)gstep);
+    // the minibatch indices (np.random.randint(0, size, B), buffer.py:98) are drawn inside k_prepare by every consumer of a batch row
+    // (same Philox counter -> same index) and recorded once in d_idx: no separate k_draw_indices node in front of the step
+    p.idx = d_idx; p.idx_rs = B; p.draw = 1; p.idx_out = d_idx;
   }
   Mat o2 = W("b_obs2");
   p.b_obs = o2.p; p.b_nobs = o2.p + (long)B * OP; p.bo_rs = o2.rs; p.b_op = OP;

@@ -81,10 +81,24 @@ __device__ __forceinline__ void orl_split4(const f32x4& v, hx4& h, hx4& l) {
 #else
 typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
 #define ORL_MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(*(const f16x4_t*)&(a), *(const f16x4_t*)&(b), c, 0, 0, 0)
-// x = hi + lo with hi = fp16(x) (round to nearest even, v_cvt_pk_f16_f32) and lo = fp16(x - hi); the remainder x - hi is exact in fp32
+// x = hi + lo with hi = fp16(x) (round to nearest even, v_cvt_pk_f16_f32) and lo = fp16(x - hi); the remainder x - hi is exact in fp32.
+// The remainder is one v_fma_mix_f32 per element (fma(float(half), -1, x) reading the half straight out of the packed hi word) instead of
+// v_cvt_f32_f16 + v_sub_f32: 8 vector instructions for four values, all of the 4.4-cycle class, against 12 (4 of them full rate) --
+// measured issue costs tools/coexec_probe.hip VKIND 13-16, profiles/r03_fp16_split_probe.txt: -21 % per split, 5 % below the bf16 split.
+// The compiler does not form the mix instruction on its own (it folds the fma back into convert + subtract).
 __device__ __forceinline__ void orl_split4(const f32x4& v, hx4& h, hx4& l) {
   h = __builtin_convertvector(v, hx4);
+#ifdef ORL_SPLIT_NO_MIX      // A/B build: convert + subtract
   l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), hx4);
+  return;
+#endif
+  const u32x2_t hb = *(const u32x2_t*)&h;
+  f32x4 r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(hb[0]), "v"(v[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(hb[0]), "v"(v[1]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r[2]) : "v"(hb[1]), "v"(v[2]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[3]) : "v"(hb[1]), "v"(v[3]));
+  l = __builtin_convertvector(r, hx4);
 }
 #endif
 __device__ __forceinline__ void orl_split1(float x, hx_t& h, hx_t& l) { h = (hx_t)x; l = (hx_t)(x - (float)h); }

@@ -60,6 +60,28 @@ __global__ void k_tick(unsigned long long* gstep) { *gstep += 1ull; }
 // 2^12 of headroom for the growth of a dz through the layers below and 2^-17 of room below before an entry's hi plane turns subnormal
 // (it then still carries 2^-24 absolute = 2^-27 of the largest entry).  One workgroup per run; max over every net's seed; exact.
 // ------------------------------------------------------------------------------------------------
+__device__ __host__ inline float orl_pow2_scale(float a) {     // 2^(3 - floor(log2 a)); 1 for 0 / non-finite
+  if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
+  int e = ilogbf(a);
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);
+  return ldexpf(1.0f, 3 - e);
+}
+// block-wide max over 256 threads; every thread receives it (NaNs are dropped by fmaxf)
+__device__ inline float block_max256(float v, float* sh4) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
+}
+// Seed kernels that run as ONE workgroup per run publish the scale themselves (`gs_out` [R], null = off): no extra launch per
+// backward pass (each k_grad_scale node costs the ~4 us every dependent kernel node costs: 10 % of a step at one run per engine).
+__device__ inline void grad_scale_publish(float amax_thread, float* sh4, float* gs_out, int r) {
+  if (!gs_out) return;                                          // uniform
+  const float a = block_max256(amax_thread, sh4);
+  if (threadIdx.x == 0) gs_out[r] = orl_pow2_scale(a);
+}
 struct GradScaleP { const float* seed; long rs, cs; int rows, cols, pitch, nets; float* out; };
 __global__ void k_grad_scale(GradScaleP p) {
   __shared__ float sh[256];
@@ -78,16 +100,7 @@ __global__ void k_grad_scale(GradScaleP p) {
     if (threadIdx.x < o) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + o]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    const float a = sh[0];
-    float s = 1.f;
-    if (a > 0.f && a < 3.0e38f) {
-      int e = ilogbf(a);
-      e = e < -100 ? -100 : (e > 100 ? 100 : e);
-      s = ldexpf(1.0f, 3 - e);
-    }
-    p.out[r] = s;
-  }
+  if (threadIdx.x == 0) p.out[r] = orl_pow2_scale(sh[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,21 +220,26 @@ struct PrepP {
   int blocks;           // blocks per run
   // dataset (sampling mode) or null -> batch slots
   const float *d_obs, *d_nobs, *d_act, *d_rew, *d_term; long n; int OP, AP;
-  const long long* idx; long idx_rs;                  // the minibatch indices of this step [R][B] (k_draw_indices or host-supplied)
+  const long long* idx; long idx_rs;                  // the minibatch indices of this step [R][B] (host-supplied), or, with `draw`:
+  int draw;                                           // indices are drawn here (orl_draw_index: one Philox call per consumer thread, same value for
+  long long* idx_out;                                 // every consumer of a batch row) and recorded in idx_out [R][B] by the rewards job
   const float *b_obs, *b_nobs, *b_act, *b_rew, *b_term; long bo_rs, ba_rs, br_rs; int b_op, b_ap;
   int B;
   unsigned long long seed; const unsigned long long* gstep; float lo, hi;
 };
 // np.random.randint(0, size, B) (buffer.py:98) on the device: one Philox call per (run, batch row), drawn ONCE per step and shared by
 // every consumer of that row (batch slots, actor / critic input rows and their N-fold repeats)
-__global__ void k_draw_indices(long long* out, long out_rs, int B, long n, unsigned long long seed, const unsigned long long* gstep) {
-  const int r = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  const unsigned long long ctr = *gstep;
+__device__ inline long long orl_draw_index(unsigned long long seed, int r, int b, unsigned long long ctr, long n) {
   Philox ph(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(r + 1));
   uint32_t o[4];
   ph((uint32_t)b, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
-  out[(long)r * out_rs + b] = (long long)(((unsigned long long)o[0] * (unsigned long long)n) >> 32);
+  return (long long)(((unsigned long long)o[0] * (unsigned long long)n) >> 32);
+}
+// (stand-alone form: orl_buffer_sample and engines without a k_prepare job table)
+__global__ void k_draw_indices(long long* out, long out_rs, int B, long n, unsigned long long seed, const unsigned long long* gstep) {
+  const int r = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  out[(long)r * out_rs + b] = orl_draw_index(seed, r, b, *gstep, n);
 }
 __global__ void k_prepare(PrepP p) {
   const int r = blockIdx.y;
@@ -260,7 +278,7 @@ __global__ void k_prepare(PrepP p) {
     const int b = jb.src_row0 + (jb.mod ? row % jb.mod : row) / jb.rep;
     const float* srow;
     if (p.d_obs) {
-      const long j = p.idx[(long)r * p.idx_rs + b];
+      const long j = p.draw ? (long)orl_draw_index(p.seed, r, b, *p.gstep, p.n) : (long)p.idx[(long)r * p.idx_rs + b];
       srow = (jb.src == PS_OBS ? p.d_obs : (jb.src == PS_NOBS ? p.d_nobs : p.d_act)) + j * (jb.src == PS_ACT ? p.AP : p.OP);
     } else {
       srow = jb.src == PS_ACT ? p.b_act + (long)r * p.ba_rs + (long)b * p.b_ap
@@ -285,12 +303,12 @@ __global__ void k_prepare(PrepP p) {
   } else if (jb.src != PS_ZERO && col < jb.ncopy) {
     const int b = jb.src_row0 + (jb.mod ? row % jb.mod : row) / jb.rep;
     if (p.d_obs) {
-      const long j = p.idx[(long)r * p.idx_rs + b];
+      const long j = p.draw ? (long)orl_draw_index(p.seed, r, b, *p.gstep, p.n) : (long)p.idx[(long)r * p.idx_rs + b];
       switch (jb.src) {
         case PS_OBS: v = p.d_obs[j * p.OP + col]; break;
         case PS_NOBS: v = p.d_nobs[j * p.OP + col]; break;
         case PS_ACT: v = p.d_act[j * p.AP + col]; break;
-        case PS_REW: v = p.d_rew[j]; break;
+        case PS_REW: v = p.d_rew[j]; if (p.draw && p.idx_out) p.idx_out[(long)r * p.idx_rs + b] = j; break;
         default: v = p.d_term[j]; break;
       }
     } else {
@@ -469,11 +487,14 @@ struct HeadBwdP {
   float* dhead; long dhead_rs;                                    // [R][B][2A]
   const RunScalars* sc; int auto_alpha; float fixed_alpha;
   int B, A;
+  float* gs_out;                                                  // split precision, B <= 256 (one block per run): dynamic scale of dhead
 };
 __global__ void k_head_bwd(HeadBwdP p) {
+  __shared__ float sh[4];
   const int r = blockIdx.y;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.B) return;
+  float amax = 0.f;
+  if (b < p.B) {
   const int A = p.A;
   const float alpha = p.auto_alpha ? p.sc[r].alpha_bwd : p.fixed_alpha;
   const float dlogp = alpha / (float)p.B;
@@ -491,9 +512,13 @@ __global__ void k_head_bwd(HeadBwdP p) {
     const float t = 2.0f * act * om / (om + 1e-6f);
     const float du = da * om + dlogp * t;
     const float dls = du * sg * e[a] - dlogp;
+    const float dl2 = (lsr >= -5.0f && lsr <= 2.0f) ? dls : 0.f;
     dh[a] = du;
-    dh[A + a] = (lsr >= -5.0f && lsr <= 2.0f) ? dls : 0.f;
+    dh[A + a] = dl2;
+    amax = fmaxf(amax, fmaxf(fabsf(du), fabsf(dl2)));
   }
+  }
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -511,7 +536,9 @@ struct CqlLossP {
   const float* logp_next; long lpn_rs;     // [R][B]   (stochastic backup)
   const float* logp_pi; const float* logp_npi; long lpp_rs;   // [R][BN]
   float* target_q; long tq_rs;             // [R][B] (tap)
-  float* part; int nblk;                   // partial sums [R][2][nblk][3] = (s_td, s_q, s_lse)
+  float* part; int nblk;                   // partial sums [R][2][nblk][4] = (s_td, s_q, s_lse, max |dq|)
+  unsigned int* ticket;                    // [R] arrival counters (zero between launches: the last arriver resets its own)
+  float* gs_out;                           // split precision: dynamic scale of dq [R], or null
   int B, N, A;
   int Bc, Br;                              // COMBO: conservative rows repeat Bc batch rows; the -w mean Q term runs over the first Br rows
   float gamma, w, T, thr;
@@ -532,7 +559,7 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
   const float log_rand = logf(powf(0.5f, (float)p.A));
   const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
   float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
-  float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
+  float s_td = 0.f, s_q = 0.f, s_lse = 0.f, amax = 0.f;
   if (blk == 0) {
     const float* t0 = p.qt + (long)r * p.qt_rs;
     const float* t1 = t0 + p.qt_cs;
@@ -551,7 +578,9 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
       const float d = q[b] - y;
       s_td += d * d;
       if (b < p.Br) s_q += q[b];
-      dq[b] = 2.0f * d / (float)B - (b < p.Br ? cs * p.w / (float)p.Br : 0.f);
+      const float g = 2.0f * d / (float)B - (b < p.Br ? cs * p.w / (float)p.Br : 0.f);
+      dq[b] = g;
+      amax = fmaxf(amax, fabsf(g));
     }
   }
   const float* lpp = p.logp_pi + (long)r * p.lpp_rs;
@@ -566,27 +595,45 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
     const float se = e0 + e1 + e2;
     s_lse += logf(se) + mx;
     dq[B + j] = gs * (e0 / se); dq[B + BN + j] = gs * (e1 / se); dq[B + 2 * BN + j] = gs * (e2 / se);
+    amax = fmaxf(amax, gs * fmaxf(e0, fmaxf(e1, e2)) / se);
   }
   s_td = block_sum256(s_td, sh);
   s_q = block_sum256(s_q, sh);
   s_lse = block_sum256(s_lse, sh);
-  if (threadIdx.x == 0) {
-    float* o = p.part + (((long)r * 2 + c) * p.nblk + blk) * 3;
-    o[0] = s_td; o[1] = s_q; o[2] = s_lse;
-  }
-}
-__global__ void k_cql_loss_fin(CqlLossP p) {
-  const int r = blockIdx.x;
+  amax = block_max256(amax, sh);
   if (threadIdx.x != 0) return;
-  RunScalars& sc = p.sc[r];
-  const int B = p.B, BN = p.Bc * p.N;
-  float cs = 1.0f, e_cla = 0.f;
-  if (p.with_lagrange) { e_cla = expf(sc.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
+  // One lane per workgroup publishes its partial sums with write-through (sc1) stores, drains them, and takes a ticket with an agent-scope
+  // atomic add; the workgroup whose add came last (told by the value the add returned) reads every partial with sc1 loads and finishes the
+  // run: metrics, Lagrange step, the dq scale.  (MI355X_MICROARCH.md, "Valid forms": sc1 stores + vmcnt(0) + agent atomic; last arriver by the
+  // returned value; sc1 loads.)  This replaces the separate one-thread k_cql_loss_fin launch -- one kernel node less per step.
+  {
+    float* o = p.part + (((long)r * 2 + c) * p.nblk + blk) * 4;
+    __hip_atomic_store(o + 0, s_td, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 1, s_q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 2, s_lse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(o + 3, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const unsigned int total = 2u * (unsigned int)p.nblk;
+  const unsigned int t = __hip_atomic_fetch_add(p.ticket + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (t != total - 1u) return;
+  __hip_atomic_store(p.ticket + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch (stream order)
+  RunScalars& scw = p.sc[r];
+  float e_cla = 0.f;
+  cs = 1.0f;
+  if (p.with_lagrange) { e_cla = expf(scw.cql_log_alpha); cs = fminf(fmaxf(e_cla, 0.f), 1e6f); }
   float raw[2];
-  for (int c = 0; c < 2; ++c) {
+  float amax_all = 0.f;
+  for (int cc = 0; cc < 2; ++cc) {
     float s_td = 0.f, s_q = 0.f, s_lse = 0.f;
-    const float* o = p.part + ((long)r * 2 + c) * p.nblk * 3;
-    for (int k = 0; k < p.nblk; ++k) { s_td += o[k * 3]; s_q += o[k * 3 + 1]; s_lse += o[k * 3 + 2]; }
+    const float* o = p.part + ((long)r * 2 + cc) * p.nblk * 4;
+    for (int k = 0; k < p.nblk; ++k) {
+      s_td += __hip_atomic_load(o + k * 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_q += __hip_atomic_load(o + k * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_lse += __hip_atomic_load(o + k * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      amax_all = fmaxf(amax_all, __hip_atomic_load(o + k * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    const int c = cc;
     float cons = (s_lse / (float)BN) * p.w * p.T - (s_q / (float)p.Br) * p.w;
     raw[c] = cons - p.thr;
     if (p.with_lagrange) cons = cs * raw[c];
@@ -594,11 +641,12 @@ __global__ void k_cql_loss_fin(CqlLossP p) {
     const int slot = c == 0 ? p.m_c1 : p.m_c2;
     p.metrics_last[(long)r * p.nm + slot] = loss; p.metrics_sum[(long)r * p.nm + slot] += loss;
   }
+  if (p.gs_out) p.gs_out[r] = orl_pow2_scale(amax_all);
   if (p.with_lagrange) {
     const float l = -(cs * raw[0] + cs * raw[1]) * 0.5f;
     const float gate = (e_cla >= 0.f && e_cla <= 1e6f) ? 1.f : 0.f;
     const float g = -(raw[0] + raw[1]) * 0.5f * e_cla * gate;
-    adam_scalar(sc.cql_log_alpha, sc.cla_m, sc.cla_v, g, p.hy->lr[3], p.b1, p.b2, p.eps, *p.gstep + 1ull);
+    adam_scalar(scw.cql_log_alpha, scw.cla_m, scw.cla_v, g, p.hy->lr[3], p.b1, p.b2, p.eps, *p.gstep + 1ull);
     p.metrics_last[(long)r * p.nm + p.m_cqla_loss] = l; p.metrics_sum[(long)r * p.nm + p.m_cqla_loss] += l;
     p.metrics_last[(long)r * p.nm + p.m_cqla] = cs; p.metrics_sum[(long)r * p.nm + p.m_cqla] += cs;
   }
@@ -742,22 +790,26 @@ struct IqlVP {
   float* dv;                            // [R][B]
   float* qmin; long qmin_rs;            // [R][B] keeps min(q_old) for the actor weights
   int B; float expectile; MetricsP m; int slot;
+  float* gs_out;                        // split precision: dynamic scale of dv [R], or null
 };
 __global__ void k_iql_v_loss(IqlVP p) {
   __shared__ float sh[4];
   const int r = blockIdx.x;
-  float s = 0.f;
+  float s = 0.f, amax = 0.f;
   for (int b = threadIdx.x; b < p.B; b += 256) {
     const float* q = p.qo + (long)r * p.qo_rs + b;
     const float qm = fminf(q[0], q[p.qo_cs]);
     const float d = qm - p.v[(long)r * p.v_rs + b];
     const float w = d > 0.f ? p.expectile : 1.0f - p.expectile;
     s += w * d * d;
-    p.dv[(long)r * p.v_rs + b] = -2.0f * w * d / (float)p.B;
+    const float g = -2.0f * w * d / (float)p.B;
+    p.dv[(long)r * p.v_rs + b] = g;
+    amax = fmaxf(amax, fabsf(g));
     p.qmin[(long)r * p.qmin_rs + b] = qm;
   }
   s = block_sum256(s, sh);
   if (threadIdx.x == 0) metric_set(p.m, r, p.slot, s / (float)p.B);
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // Q losses + advantage weights: y = r + gamma (1-d) V_new(s') ; dq_i = 2 (q_i - y)/B ;
@@ -771,11 +823,12 @@ struct IqlQP {
   float* exp_a; long ea_rs;             // [R][B]
   float* target_q; long tq_rs;
   int B; float gamma, beta; MetricsP m; int slot_q1, slot_q2;
+  float* gs_out;                        // split precision: dynamic scale of dq [R], or null
 };
 __global__ void k_iql_q_loss(IqlQP p) {
   __shared__ float sh[4];
   const int r = blockIdx.x;
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, amax = 0.f;
   for (int b = threadIdx.x; b < p.B; b += 256) {
     const float* v2 = p.v2 + (long)r * p.v2_rs;
     const float y = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * v2[p.B + b];
@@ -785,11 +838,13 @@ __global__ void k_iql_q_loss(IqlQP p) {
     const float d1 = q[0] - y, d2 = q[p.q_cs] - y;
     s1 += d1 * d1; s2 += d2 * d2;
     dq[0] = 2.0f * d1 / (float)p.B; dq[p.q_cs] = 2.0f * d2 / (float)p.B;
+    amax = fmaxf(amax, 2.0f * fmaxf(fabsf(d1), fabsf(d2)) / (float)p.B);
     p.exp_a[(long)r * p.ea_rs + b] = fminf(expf((p.qmin[(long)r * p.qmin_rs + b] - v2[b]) * p.beta), 100.0f);
   }
   s1 = block_sum256(s1, sh);
   s2 = block_sum256(s2, sh);
   if (threadIdx.x == 0) { metric_set(p.m, r, p.slot_q1, s1 / (float)p.B); metric_set(p.m, r, p.slot_q2, s2 / (float)p.B); }
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // actor: mu = tanh(m_raw), sigma = exp(sigma_param); L = -mean(exp_a * logp(a_data)); writes d m_raw and the
@@ -802,6 +857,7 @@ struct IqlAP {
   float* dmraw;                         // [R][B][A]
   float* g_sigma; long gs_rs;           // [R][A] gradient slab 0 of sigma_param
   int B, A; MetricsP m; int slot;
+  float* gs_out;                        // split precision: dynamic scale of dmraw [R], or null
 };
 __global__ void k_iql_actor_loss(IqlAP p) {
   __shared__ float sh[4];
@@ -810,7 +866,7 @@ __global__ void k_iql_actor_loss(IqlAP p) {
   const int A = p.A;
   for (int a = threadIdx.x; a < A; a += 256) gsig[a] = 0.f;
   __syncthreads();
-  float s = 0.f;
+  float s = 0.f, amax = 0.f;
   const float* sp = p.sigma_param + (long)r * p.sp_rs;
   for (int b = threadIdx.x; b < p.B; b += 256) {
     const float ea = p.exp_a[(long)r * p.ea_rs + b];
@@ -821,7 +877,9 @@ __global__ void k_iql_actor_loss(IqlAP p) {
       const float ls = sp[a], sg = expf(ls), var = sg * sg;
       const float d = p.act[(long)r * p.act_rs + (long)b * p.apitch + a] - mu;
       lp += -(d * d) / (2.0f * var) - ls - ORL_LOG_SQRT_2PI;
-      p.dmraw[(long)r * p.mraw_rs + (long)b * A + a] = dlogp * d / var * (1.0f - mu * mu);
+      const float g = dlogp * d / var * (1.0f - mu * mu);
+      p.dmraw[(long)r * p.mraw_rs + (long)b * A + a] = g;
+      amax = fmaxf(amax, fabsf(g));
       atomicAdd(&gsig[a], dlogp * (d * d / var - 1.0f));
     }
     s += ea * lp;
@@ -830,6 +888,7 @@ __global__ void k_iql_actor_loss(IqlAP p) {
   __syncthreads();
   for (int a = threadIdx.x; a < A; a += 256) p.g_sigma[(long)r * p.gs_rs + a] = gsig[a];
   if (threadIdx.x == 0) metric_set(p.m, r, p.slot, -s / (float)p.B);
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // ================================================================================================
@@ -867,6 +926,7 @@ struct TdLossP {
   float gamma; int sum_over_k;                   // EDAC: one metric = sum_k mean_b ; else metric slot per critic
   const RunScalars* sc; int use_alpha; int auto_alpha; float fixed_alpha;
   MetricsP m; int slot0; float last_actor_loss_slot_unused;
+  float* gs_out;                                 // split precision: dynamic scale of dq [R], or null
 };
 __global__ void k_td_loss(TdLossP p) {
   __shared__ float sh[4];
@@ -886,7 +946,7 @@ __global__ void k_td_loss(TdLossP p) {
     tq[b] = p.rew[(long)r * p.bt_rs + b] + p.gamma * (1.0f - p.term[(long)r * p.bt_rs + b]) * nq;
   }
   __syncthreads();
-  float total = 0.f;
+  float total = 0.f, amax = 0.f;
   for (int c = 0; c < p.K; ++c) {
     const float* q = p.q + (long)r * p.q_rs + (long)c * p.q_cs;
     float* dq = p.dq + (long)r * p.q_rs + (long)c * p.q_cs;
@@ -895,12 +955,14 @@ __global__ void k_td_loss(TdLossP p) {
       const float d = q[b] - tq[b];
       s += d * d;
       dq[b] = 2.0f * d / (float)B;
+      amax = fmaxf(amax, 2.0f * fabsf(d) / (float)B);
     }
     s = block_sum256(s, sh);
     if (p.sum_over_k) total += s / (float)B;
     else if (threadIdx.x == 0) metric_set(p.m, r, p.slot0 + c, s / (float)B);
   }
   if (p.sum_over_k && threadIdx.x == 0) metric_set(p.m, r, p.slot0, total);
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // TD3BC actor objective pieces: lambda = alpha / mean|q| ; L = -lambda mean(q) + mean((a_pi - a)^2) ; dq = -lambda/B
@@ -910,6 +972,7 @@ struct Td3ActorP {
   const float* xa; long xa_rs; int XP, od;  // pi(s) in xa[:, od:]
   const float* act; long act_rs; int apitch;
   int B, A; float alpha; RunScalars* sc; MetricsP m; int slot;
+  float* gs_out;                         // split precision: dynamic scale of dq (= lambda / B on every row) [R], or null
 };
 __global__ void k_td3_actor_loss(Td3ActorP p) {
   __shared__ float sh[4];
@@ -930,6 +993,7 @@ __global__ void k_td3_actor_loss(Td3ActorP p) {
     const float loss = -lmbda * (sq / (float)p.B) + sbc / (float)(p.B * p.A);
     p.sc[r].last_actor_loss = loss;
     metric_set(p.m, r, p.slot, loss);
+    if (p.gs_out) p.gs_out[r] = orl_pow2_scale(fabsf(lmbda) / (float)p.B);
   }
 }
 // critic-only steps report the last actor loss (td3bc.py:120)
@@ -1091,11 +1155,12 @@ struct EdacGP {
   const float* g; long g_rs, g_cs; int gpitch;   // [R][K][B][A]
   float* gamma;                                   // same layout
   int B, K, A; float eta; MetricsP m; int slot;
+  float* gs_out;                                  // split precision: dynamic scale of gamma [R], or null
 };
 __global__ void k_edac_gamma(EdacGP p) {
   __shared__ float sh[4];
   const int r = blockIdx.x;
-  float sl = 0.f;
+  float sl = 0.f, amax = 0.f;
   for (int b = threadIdx.x; b < p.B; b += 256) {
     float S[32];
     for (int a = 0; a < p.A; ++a) S[a] = 0.f;
@@ -1121,10 +1186,15 @@ __global__ void k_edac_gamma(EdacGP p) {
       float gc = 0.f;
       for (int a = 0; a < p.A; ++a) gc += gk[a] * cf * (S[a] - gk[a] / nk);
       const float safe = nrm > 0.f ? nrm : 1.0f;
-      for (int a = 0; a < p.A; ++a) ok[a] = cf * (S[a] - gk[a] / nk) / nk - gk[a] * (gc / (nk * nk * safe));
+      for (int a = 0; a < p.A; ++a) {
+        const float v = cf * (S[a] - gk[a] / nk) / nk - gk[a] * (gc / (nk * nk * safe));
+        ok[a] = v;
+        amax = fmaxf(amax, fabsf(v));
+      }
     }
   }
   sl = block_sum256(sl, sh);
+  grad_scale_publish(amax, sh, p.gs_out, r);
   if (threadIdx.x == 0) {
     const float lg = p.eta * (sl / (float)p.B) / (float)(p.K - 1);
     p.m.last[(long)r * p.m.nm + p.slot] += lg; p.m.sum[(long)r * p.m.nm + p.slot] += lg;

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Long-horizon golden vectors: 200 teacher-forced steps of the REAL reference's ``CQLPolicy.learn``
+(/root/reference/offlinerlkit/policy/model_free/cql.py:87-207) at the north-star shape, storing the loss trajectory only -- once from the
+initial state of ``synth.cql_case_inputs("cql_halfcheetah_long")`` and once per PERTURBED initial state (every trainable parameter times
+(1 + eps), eps in +-1e-7, +-2e-7: about one fp32 ulp).  The spread of the perturbed trajectories around the unperturbed one is the
+reference's OWN divergence envelope: how far two runs of the same reference drift apart when their parameters differ in the last bit.  An
+engine whose arithmetic differs from torch's in rounding only must stay inside a small multiple of that envelope
+(tests/test_gpu_long_horizon.py); one whose arithmetic is coarser leaves it.
+
+Build container only (the reference does not exist on the GPU box); only arrays of numbers are stored.
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_long_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+import make_golden as mg  # noqa: E402
+import synth  # noqa: E402
+
+CASE = "cql_halfcheetah_long"
+PERTURBATIONS = (1e-7, -1e-7, 2e-7, -2e-7)
+
+
+def run(ref, eps):
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import cql as ocql
+    c, st, batches, noises = synth.cql_case_inputs(CASE)
+    cfg = ocql.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"], num_repeat_actions=c["N"])
+    cfg.update(c["over"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    scale = np.float32(1.0 + eps)
+
+    def pert(net):
+        return OrderedDict((k, (v * scale).astype(np.float32)) for k, v in net.items())
+    actor = ref.ActorProb(ref.MLP(od, hid), ref.TanhDiagGaussian(hid[-1], ad, unbounded=True, conditioned_sigma=True))
+    c1, c2 = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid))
+    mg._load(actor, pert(st["actor"])); mg._load(c1, pert(st["critic1"])); mg._load(c2, pert(st["critic2"]))
+    log_alpha = torch.tensor(st["log_alpha"].copy(), requires_grad=True)
+    alpha = (cfg["target_entropy"], log_alpha, torch.optim.Adam([log_alpha], lr=cfg["alpha_lr"]))
+    pol = ref.CQLPolicy(actor, c1, c2, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]), torch.optim.Adam(c1.parameters(), lr=cfg["critic_lr"]),
+                        torch.optim.Adam(c2.parameters(), lr=cfg["critic_lr"]), action_space=mg._ActionSpace(ad), tau=cfg["tau"], gamma=cfg["gamma"],
+                        alpha=alpha, cql_weight=cfg["cql_weight"], temperature=cfg["temperature"], max_q_backup=cfg["max_q_backup"],
+                        deterministic_backup=cfg["deterministic_backup"], with_lagrange=cfg["with_lagrange"],
+                        lagrange_threshold=cfg["lagrange_threshold"], cql_alpha_lr=cfg["cql_alpha_lr"], num_repeart_actions=cfg["num_repeat_actions"])
+    mg._load(pol.critic1_old, st["critic1_old"]); mg._load(pol.critic2_old, st["critic2_old"])       # (targets unperturbed)
+    with torch.no_grad():
+        pol.cql_log_alpha.copy_(torch.tensor(st["cql_log_alpha"]))
+    pol.train()
+    feeder = mg.NoiseFeeder(); feeder.install()
+    losses, keys = [], None
+    try:
+        for b, n in zip(batches, noises):
+            feeder.normal_q = [n["eps_actor"], n["eps_next"], n["eps_pi"], n["eps_next_pi"]]
+            feeder.uniform_q = [n["u_rand"]]
+            res = pol.learn(mg._tb(b))
+            keys = keys or list(res.keys())
+            losses.append([res[x] for x in keys])
+    finally:
+        feeder.uninstall()
+    return np.array(losses, dtype=np.float64), keys
+
+
+def main():
+    ref = mg._import_reference()
+    torch.set_num_threads(4)
+    out = OrderedDict()
+    t0 = time.time()
+    base, keys = run(ref, 0.0)
+    out["losses"] = base
+    out["loss_keys"] = np.array(keys)
+    out["perturbations"] = np.array(PERTURBATIONS)
+    for i, eps in enumerate(PERTURBATIONS):
+        out[f"losses_perturbed{i}"], _ = run(ref, eps)
+        d = np.abs(out[f"losses_perturbed{i}"] - base) / np.maximum(np.abs(base), 1e-2 * np.abs(base).max(axis=0))
+        print(f"eps {eps:+.0e}: max relative deviation from the unperturbed run by step 20 / 50 / 100 / 200: "
+              f"{d[:20].max():.2e} {d[:50].max():.2e} {d[:100].max():.2e} {d.max():.2e}")
+    path = os.path.join(HERE, f"{CASE}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -182,9 +182,16 @@ CQL_EXTRA_CASES = {
 }
 
 
+# Long teacher-forced window (VERDICT r2 item 5 / SURVEY §7.3.6): 200 steps of the north-star CQL shape.  Fixture: losses only, of the
+# reference and of perturbed references (tests/golden/make_long_golden.py); the inputs are regenerated from the seed.
+CQL_LONG_CASES = {
+    "cql_halfcheetah_long": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, N=10, steps=200, seed=9, over={}),
+}
+
+
 def cql_case_inputs(case):
     """(cfg_overrides, init_state, [batch_k], [noise_k]) for a CQL case."""
-    c = CQL_CASES[case] if case in CQL_CASES else CQL_EXTRA_CASES[case]
+    c = CQL_CASES[case] if case in CQL_CASES else (CQL_EXTRA_CASES[case] if case in CQL_EXTRA_CASES else CQL_LONG_CASES[case])
     rng = np.random.RandomState(c["seed"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
     state = OrderedDict()

@@ -15,7 +15,7 @@ NETS = {"actor": 0, "critic1": 1, "critic2": 2, "critic1_old": 3, "critic2_old":
 def make_engine(case, n_runs=1, precision=0):
     from offlinerlkit import _engine
     cfg, st, batches, noises = cql_oracle_setup(case)
-    c = synth.CQL_CASES[case] if case in synth.CQL_CASES else synth.CQL_EXTRA_CASES[case]
+    c = next(d[case] for d in (synth.CQL_CASES, synth.CQL_EXTRA_CASES, synth.CQL_LONG_CASES) if case in d)
     over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs,
                 num_repeat_actions=c["N"], target_entropy=cfg["target_entropy"], auto_alpha=int(cfg["auto_alpha"]),
                 alpha=cfg["alpha"], max_q_backup=int(cfg["max_q_backup"]), deterministic_backup=int(cfg["deterministic_backup"]),

@@ -22,7 +22,7 @@ def test_rccl_world_size_one_group_gathers_the_metric_table():
     env.pop("MASTER_PORT", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rccl-check"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL ")]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL {")]          # (RCCL itself prints "RCCL version : ...")
     assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[0][5:])
     assert out["backend"] == "nccl" and out["world"] == 1

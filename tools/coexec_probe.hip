@@ -36,6 +36,14 @@ __device__ __forceinline__ void valu_op(float& x, float s) {
   asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, 0, %0, vcc" : "+v"(x) : "v"(s) : "vcc");
 #elif VKIND == 11
   asm volatile("v_med3_i32 %0, %0, 0, 1" : "+v"(x));
+#elif VKIND == 13      // x - float(half in the low / high 16 bits of s): the lo plane of the fp16 split without a separate v_cvt_f32_f16
+  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(x) : "v"(s));
+#elif VKIND == 14
+  asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(s));
+#elif VKIND == 15
+  asm volatile("v_cvt_f32_f16 %0, %1" : "+v"(x) : "v"(s));
+#elif VKIND == 16
+  asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(x) : "v"(s));
 #else
   asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(s));
 #endif
