@@ -292,6 +292,12 @@ def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump
                 table=[dict(name=t["name"], ms_per_step=t["total_ms"] / steps, launches_per_step=t["launches"] / steps) for t in table[:12]])
     if flops_step is not None and value is not None:
         roof["step_frac_of_mlp_gemm_roofline"] = value * flops_step / (peak * 1e12)
+    # the whole step against the HBM roof: algorithmic bytes of every launch (operands read once, results written once) over the eager step time
+    tot_ms = sum(t["total_ms"] for t in table)
+    tot_bytes = sum(t["bytes_per_launch"] * t["launches"] for t in table)
+    roof["whole_step_hbm"] = dict(algorithmic_gb_per_step=tot_bytes / steps / 1e9, achieved_gbps=tot_bytes / (tot_ms * 1e-3) / 1e9, peak_gbps=8000.0,
+                                  frac=tot_bytes / (tot_ms * 1e-3) / 1e9 / 8000.0,
+                                  note="launches without a byte model (Adam, sampling, loss kernels) count as zero bytes: a lower bound")
     return roof
 
 

@@ -205,6 +205,10 @@ struct GemmP {
   // memory -- the scale k_grad_scale chose for the gradient matrices of the backward pass this operand belongs to.
   float a_scale, b_scale;
   const float* a_dscale; const float* b_dscale;
+  // z-major workgroup mapping (set by launch_inst for batched problems with few tiles each): gridDim.x = 8 * (tiles * ksplit),
+  // gridDim.z = ceil(nz / 8); problem z = 8 * blockIdx.z + (blockIdx.x & 7), item = blockIdx.x >> 3 -- every tile of one problem has
+  // the same linear-id residue mod 8, i.e. (round-robin placement) the same XCD and its L2, instead of one XCD per tile
+  int zmajor, nz_total;
 };
 
 enum { W0_XP = 28 };     // LDS pitch of the X tile staged by the fused layer-0 weight gradient (floats)

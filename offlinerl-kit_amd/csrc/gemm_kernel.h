@@ -2,6 +2,7 @@
 // Included only by the gemm_inst_*.hip translation units.
 #pragma once
 #include "gemm.h"
+#include <cstdlib>
 
 namespace orl {
 
@@ -218,7 +219,8 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   hx_t* Bh = Ah + 2 * 2 * TM * PITCH;
 
   const int tid = threadIdx.x;
-  const int z = blockIdx.z;
+  const int z = p.zmajor ? (int)(blockIdx.z * 8 + (blockIdx.x & 7)) : (int)blockIdx.z;
+  if (p.zmajor && z >= p.nz_total) return;
   const int z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   // XCD-aware tile mapping (MI355X: 8 XCDs with private L2s; workgroups are dealt round-robin over them by linear
   // id, and gridDim.x is padded to a multiple of 8 so the XCD of a block is blockIdx.x % 8 for every z).  Logical work
@@ -228,8 +230,11 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   const int tiles_n = (p.N + TN - 1) / TN;
   const int tiles = ((p.M + TM - 1) / TM) * tiles_n;
   const int total = tiles * p.ksplit;
+  // Batched problems with FEW tiles each (the 256-row products of many nets: 4 tiles of 128 x 128) use the z-major mapping instead
+  // (GemmP::zmajor): with the item-major one the 4 tiles of a net landed on 4 different XCDs and every tile fetched its operand panels
+  // from HBM -- PMC on EDAC's edac.t / edac.wgrad / critic.bwd.wgrad launches: 1.85 / 1.35 GB read against 0.7 - 1.0 GB algorithmic.
   const int per_xcd = gridDim.x >> 3;
-  const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const int item = p.zmajor ? (int)(blockIdx.x >> 3) : (int)((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3));
   if (item >= total) return;
   const int ks = item / tiles, tile = item - ks * tiles;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
@@ -623,6 +628,12 @@ template <class CFG, int LA, int LB, int PA, int PB, int EPI, int PREC = P_F32>
 static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
   const int tiles = ((p.M + CFG::TM - 1) / CFG::TM) * ((p.N + CFG::TN - 1) / CFG::TN);
   dim3 grid((tiles * p.ksplit + 7) & ~7, 1, nz), block(CFG::NT);     // padded to the 8 XCDs (see the kernel's tile mapping)
+  GemmP q = p;
+  static const int zm_max = [] { const char* f = getenv("ORL_GEMM_ZMAJOR_MAX"); return f ? atoi(f) : 16; }();   // 0 disables (A/B runs)
+  if (nz >= 8 && tiles * p.ksplit > 1 && tiles * p.ksplit <= zm_max) {   // few tiles per problem, many problems: keep a problem on one XCD
+    q.zmajor = 1; q.nz_total = nz;
+    grid = dim3(8 * tiles * p.ksplit, 1, (nz + 7) / 8);
+  }
   size_t lds = CFG::lds_bytes(PREC);
   if (CFG::epi_lds_bytes() <= CFG::epi_lds_limit(PREC)) lds = std::max(lds, CFG::epi_lds_bytes());   // staged C tile (kernel: LDS_EPI_FITS)
   if (EPI == E_MASK && p.w0_out) lds = std::max(lds, sizeof(float) * ((size_t)CFG::TM * (CFG::TN + 4) + (size_t)CFG::TM * W0_XP));
@@ -635,7 +646,7 @@ static inline hipError_t launch_inst(const GemmP& p, int nz, hipStream_t st) {
       raised_to.store(lds, std::memory_order_release);
     }
   }
-  hipLaunchKernelGGL(kern, grid, block, lds, st, p);
+  hipLaunchKernelGGL(kern, grid, block, lds, st, q);
   return hipGetLastError();
 }
 
