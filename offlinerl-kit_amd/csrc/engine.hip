@@ -600,7 +600,11 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
   // many batched nets fill the CUs without split-K, but workgroups that all stream thousands of rows from the same offset of
   // equally strided matrices run 2x slower (measured at 256 nets x 7936 rows, fp32: 12.8 -> 5.4 ms): keep >= 4 k-ranges
   if (Krows >= 4096) ks = std::max(ks, long_min);
-  if (cfg == CFG_SQ && Krows < 1024 && kchunks >= 8) ks = std::max(ks, 2);      // 256-row wgrads of many nets: two k-ranges measured 1.5x faster
+  static const int small_ks = [] { const char* f = getenv("ORL_WGRAD_SMALL_KS"); return (f && atoi(f) > 0) ? atoi(f) : 1; }();
+  // 256-row wgrads of many nets: round 2 measured two k-ranges 1.5x faster than one -- with the item-major workgroup mapping, where the four
+  // tiles of a net sat on four XCDs.  With the z-major mapping (gemm_kernel.h) one range wins: EDAC 15.4k -> 16.9k steps/s, IQL +2.5 %,
+  // TD3+BC +2.5 % at 128 runs (Adam reads half the slabs).  ORL_WGRAD_SMALL_KS=2 restores the old rule for A/B runs.
+  if (cfg == CFG_SQ && Krows < 1024 && kchunks >= 8) ks = std::max(ks, small_ks);
   ks = std::max(1, std::min(ks, std::min(cap, kchunks)));
   while (ks > 1 && (kchunks + ks - 1) / ks < 2) --ks;
   return ks;
