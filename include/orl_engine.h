@@ -126,6 +126,10 @@ typedef struct orl_config {
    *   ws_cus        CUs one launch spreads over, 8..256 (0 = 256).
    * The environment variables ORL_WS_ONE_ROUND / ORL_WS_CUS, when set, override these fields; they are read once, in orl_engine_create. */
   int32_t ws_one_round, ws_cus;
+  /* nn.Dropout(p) behind every hidden ReLU of the ACTOR backbone (nets/mlp.py:16-24; run_iql.py:34,106 builds only the actor backbone with
+   * --dropout_rate).  IQL only; 0 = none.  Active in learn() (policy.train() mode, iql.py:122), never in select_action (eval mode).
+   * Teacher-forced runs pass the keep masks (0 / 1) of the reference's draws as noise slots 0 .. n_hidden - 1. */
+  float actor_dropout;
   /* optional caller-owned parameter arena (device pointer, orl_arena_floats()
    * floats) so that framework tensors can alias engine parameters; NULL = the
    * engine allocates with hipMalloc. */

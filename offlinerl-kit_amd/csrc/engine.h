@@ -191,6 +191,12 @@ struct Engine {
   void prof_end();
   int assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep);
   int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
+  // the same with nn.Dropout(p) behind every hidden ReLU (keep masks in `masks[i]`, [R][M][H_i]); layer by layer on the tiled kernels
+  int mlp_forward_dropout(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag, float p,
+                          const std::vector<Mat>& masks);
+  int scale_inplace(const Mat& m, int rows, int cols, int nets, float s, const Mat* mask, const char* tag);
+  bool no_ws = false;          // set while a dropout forward is enqueued: its layers must exist one by one
+  float bwd_scale = 1.0f;      // mlp_backward: every masked dz of the pass is multiplied by this (1 / (1 - p) of a dropout backbone)
 
   int enqueue_sample();
   int enqueue_noise();

@@ -37,7 +37,9 @@ static void add_tensor(NetLayout& l, const std::string& name, long off, std::ini
 
 enum TailKind { TAIL_CRITIC, TAIL_TANH_GAUSS, TAIL_GAUSS, TAIL_DET };
 
-static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind tail, int act_dim) {
+// seq_step: distance of consecutive Linear layers in the backbone's nn.Sequential -- 2 for [Linear, ReLU], 3 when every ReLU is followed by
+// nn.Dropout (nets/mlp.py:20-23): the state_dict keys are backbone.model.{0, 3, 6, ...} then
+static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind tail, int act_dim, int seq_step = 2) {
   NetLayout l;
   l.present = true;
   l.in_dim = in_dim;
@@ -47,10 +49,10 @@ static NetLayout make_mlp_layout(int in_dim, const int* hidden, int L, TailKind 
   for (int i = 0; i < L; ++i) {
     l.H[i] = hidden[i];
     l.w_off[i] = off;
-    add_tensor(l, "backbone.model." + std::to_string(2 * i) + ".weight", off, {hidden[i], d});
+    add_tensor(l, "backbone.model." + std::to_string(seq_step * i) + ".weight", off, {hidden[i], d});
     off += (long)hidden[i] * d;
     l.b_off[i] = off;
-    add_tensor(l, "backbone.model." + std::to_string(2 * i) + ".bias", off, {hidden[i]});
+    add_tensor(l, "backbone.model." + std::to_string(seq_step * i) + ".bias", off, {hidden[i]});
     off += hidden[i];
     d = hidden[i];
   }
@@ -161,7 +163,7 @@ static int build_layouts(const orl_config& c, NetLayout* lay, long* net_off, boo
       train(ORL_NET_VAE_DEC, make_vae_layout(false, od + c.vae_latent, c.vae_hidden, ad));
     }
   } else if (c.algo == ORL_ALGO_IQL) {
-    train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_GAUSS, ad));
+    train(ORL_NET_ACTOR, make_mlp_layout(od, c.hidden, L, TAIL_GAUSS, ad, c.actor_dropout > 0.f ? 3 : 2));
     train(ORL_NET_CRITIC1, crit); train(ORL_NET_CRITIC2, crit);
     train(ORL_NET_CRITIC_V, make_mlp_layout(od, c.hidden, L, TAIL_CRITIC, ad));
     target(ORL_NET_CRITIC1_OLD, crit); target(ORL_NET_CRITIC2_OLD, crit);
@@ -354,7 +356,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
-  if (epi == E_BIAS_RELU && ws_precision_ok() && !force_scalar && in_row0 == 0 && in_rows == in &&
+  if (epi == E_BIAS_RELU && ws_precision_ok() && !no_ws && !force_scalar && in_row0 == 0 && in_rows == in &&
       Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
@@ -741,6 +743,27 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
 }
 
+int Engine::scale_inplace(const Mat& m, int rows, int cols, int nets, float s, const Mat* mask, const char* tag) {
+  ORL_LAUNCH(tag, k_dropout, dim3((unsigned)(((long)rows * cols + 255) / 256), nets, R), dim3(256), m.p, m.rs, m.cs, m.pitch,
+             (const float*)(mask ? mask->p : nullptr), mask ? mask->rs : 0L, rows, cols, s);
+  return 0;
+}
+
+int Engine::mlp_forward_dropout(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag, float p,
+                                const std::vector<Mat>& masks) {
+  const NetLayout& l = *nr.lay;
+  const std::string t = tag;
+  const float inv_keep = 1.0f / (1.0f - p);
+  struct Scope { Engine* e; ~Scope() { e->no_ws = false; } } scope{this};
+  no_ws = true;                                            // one launch per layer: the dropout sits between them
+  for (int i = 0; i < l.L; ++i) {
+    if (linear_fwd(i == 0 ? X : hs[i - 1], M, nr, i, hs[i], E_BIAS_RELU, nullptr, (t + ".fwd" + std::to_string(i)).c_str())) return -1;
+    if (scale_inplace(hs[i], M, l.layer_out(i), nr.nz1, inv_keep, &masks[i], (t + ".dropout" + std::to_string(i)).c_str())) return -1;
+    if (hs[i].bits) bits_live.erase(hs[i].bits);           // the packed ReLU mask predates the dropout: the backward reads 1[h > 0] from the values
+  }
+  return linear_fwd(hs[l.L - 1], M, nr, l.L, out, E_BIAS, nullptr, (t + ".tail").c_str());
+}
+
 // Adam segment table: one (end offset, slab count) pair per weight tensor and per bias tensor
 static std::vector<std::pair<long, int>> make_segs(const NetLayout& l, const std::vector<int>& ksW, const std::vector<int>& ksB) {
   std::vector<std::pair<long, int>> s;
@@ -777,6 +800,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   if (rank1) cur = DY::virt(hs[L - 1], dTail);
   else {
     if (e->linear_dgrad(DY::plain(dTail), M, nr, L, 0, l.layer_in(L), &hs[L - 1], dz[L - 1], (t + ".dgrad_tail").c_str())) return -1;
+    if (e->bwd_scale != 1.0f && e->scale_inplace(dz[L - 1], M, l.layer_out(L - 1), nr.nz1, e->bwd_scale, nullptr, (t + ".dropout_bwd").c_str())) return -1;
     cur = DY::plain(dz[L - 1]);
   }
   for (int i = L - 1; i >= 0; --i) {
@@ -798,6 +822,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
       if (e->linear_dgrad(cur, M, nr, i, 0, l.layer_in(i), &hs[i - 1], dz[i - 1], (t + ".dgrad" + std::to_string(i)).c_str(),
                           (want_w && i == 1) ? &X : nullptr, want_dx, &w0_slabs)) return -1;
       if (w0_slabs > 0) { w0_done = true; ks[0] = w0_slabs; }
+      if (e->bwd_scale != 1.0f && e->scale_inplace(dz[i - 1], M, l.layer_out(i - 1), nr.nz1, e->bwd_scale, nullptr, (t + ".dropout_bwd").c_str())) return -1;
       cur = DY::plain(dz[i - 1]);
     } else if (want_dx) {
       if (e->linear_dgrad(cur, M, nr, 0, dx_col0, dx_ncols, nullptr, *dX, (t + ".dgrad_x").c_str())) return -1;
@@ -872,7 +897,9 @@ int Engine::init(const orl_config& c) {
   if (c.device < 0 || c.device >= ndev) return fail("bad device ordinal");
   dev = c.device;
   ORL_HIP(hipSetDevice(dev));
-  if (c.precision != 0 && c.precision != 1) return fail("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)");
+  if (c.precision != 0 && c.precision != 1) return fail("precision must be 0 (fp32 MFMA) or 1 (split-precision MFMA)");
+  if (c.actor_dropout != 0.f && (c.algo != ORL_ALGO_IQL || !(c.actor_dropout > 0.f && c.actor_dropout < 1.f)))
+    return fail("actor_dropout: supported for IQL only (run_iql.py --dropout_rate), 0 < p < 1");
   if (build_layouts(c, lay, net_off, net_is_target, &P_train, &P_tgt)) return -1;
   ORL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   R = c.n_runs; B = c.batch_size; od = c.obs_dim; ad = c.act_dim;
@@ -962,8 +989,8 @@ int Engine::enqueue_noise() {
   uint32_t sid = 1;
   for (auto& s : noise_slots) {
     const long n = ws_len.at(s.name);
-    ORL_LAUNCH("noise", k_noise, dim3((unsigned)((n / 4 + 256) / 256), R), dim3(256), W(s.name).p, n, s.kind, cfg.act_low,
-               cfg.act_high, cfg.seed, (const unsigned long long*)gstep, sid);
+    ORL_LAUNCH("noise", k_noise, dim3((unsigned)((n / 4 + 256) / 256), R), dim3(256), W(s.name).p, n, s.kind,
+               s.kind == 2 ? 1.0f - cfg.actor_dropout : cfg.act_low, cfg.act_high, cfg.seed, (const unsigned long long*)gstep, sid);
     ++sid;
   }
   return 0;

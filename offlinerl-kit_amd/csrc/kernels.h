@@ -175,7 +175,7 @@ __global__ void k_fill(float* p, long n, float v) {
   if (i < n) p[i] = v;
 }
 
-// device noise: fills `n` floats per run with N(0,1) (kind 0) or U[lo,hi) (kind 1)
+// device noise: fills `n` floats per run with N(0,1) (kind 0), U[lo,hi) (kind 1) or dropout keep masks 1[U(0,1) < lo] (kind 2, lo = 1 - p)
 __global__ void k_noise(float* out, long n_per_run, int kind, float lo, float hi, unsigned long long seed,
                         const unsigned long long* gstep, uint32_t stream_id) {
   const int r = blockIdx.y;
@@ -186,9 +186,22 @@ __global__ void k_noise(float* out, long n_per_run, int kind, float lo, float hi
   ph((uint32_t)(i4 >> 2), (uint32_t)r | (stream_id << 16), (uint32_t)(*gstep), 0xA5u ^ (uint32_t)((*gstep) >> 32), o);
   float v[4];
   if (kind == 0) { box_muller(o[0], o[1], v[0], v[1]); box_muller(o[2], o[3], v[2], v[3]); }
-  else { for (int k = 0; k < 4; ++k) v[k] = lo + (hi - lo) * u01(o[k]); }
+  else if (kind == 1) { for (int k = 0; k < 4; ++k) v[k] = lo + (hi - lo) * u01(o[k]); }
+  else { for (int k = 0; k < 4; ++k) v[k] = u01(o[k]) < lo ? 1.0f : 0.0f; }
   float* dst = out + (long)r * n_per_run;
   for (int k = 0; k < 4; ++k) if (i4 + k < n_per_run) dst[i4 + k] = v[k];
+}
+
+// nn.Dropout in training mode (nets/mlp.py:22-23) on a hidden activation, in place: h = keep ? h / (1 - p) : 0 with the keep mask of the
+// step (0 / 1 floats [R][rows][cols]: teacher-forced from the reference's draws or k_noise kind 2); `mask == nullptr`: plain scaling by `s`
+// (the 1 / (1 - p) factor of the backward pass on a masked dz).  grid (ceil(rows * cols / 256), nets, R)
+__global__ void k_dropout(float* h, long h_rs, long h_cs, int pitch, const float* mask, long m_rs, int rows, int cols, float s) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)rows * cols) return;
+  const int row = (int)(e / cols), c = (int)(e - (long)row * cols);
+  float* x = h + blockIdx.z * h_rs + blockIdx.y * h_cs + (long)row * pitch + c;
+  const float k = mask ? mask[blockIdx.z * m_rs + e] : 1.0f;
+  *x = *x * k * s;
 }
 
 // ------------------------------------------------------------------------------------------------

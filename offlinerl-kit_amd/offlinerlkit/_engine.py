@@ -56,7 +56,7 @@ class OrlConfig(C.Structure):
         ("num_critics", C.c_int32), ("eta", C.c_float),
         ("cql_cons_row0", C.c_int32), ("cql_cons_rows", C.c_int32), ("cql_real_rows", C.c_int32),
         ("vae_hidden", C.c_int32), ("vae_latent", C.c_int32), ("mcq_lambda", C.c_float), ("behavior_lr", C.c_float),
-        ("ws_one_round", C.c_int32), ("ws_cus", C.c_int32),
+        ("ws_one_round", C.c_int32), ("ws_cus", C.c_int32), ("actor_dropout", C.c_float),
         ("external_arena", C.c_void_p),
     ]
 

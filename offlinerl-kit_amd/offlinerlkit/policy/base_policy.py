@@ -41,12 +41,15 @@ class BasePolicy(nn.Module):
         raise NotImplementedError
 
 
-def _backbone_dims(backbone: MLP):
+def _backbone_dims(backbone: MLP, allow_dropout: bool = False):
+    """(input width, hidden widths) of an MLP backbone.  ``dropout_rate`` (nets/mlp.py:16-24) is supported where the reference's launchers
+    use it -- the actor backbone of IQL (run_iql.py:34,106) -- and refused elsewhere."""
     lins = backbone.linear_layers() if hasattr(backbone, "linear_layers") else [m for m in backbone.model if isinstance(m, nn.Linear)]
     if not lins:
         raise ValueError("backbone has no Linear layers")
-    if getattr(backbone, "dropout_rate", None) is not None:
-        raise NotImplementedError("dropout in the backbone is not supported by the HIP engine")
+    if getattr(backbone, "dropout_rate", None) is not None and not allow_dropout:
+        raise NotImplementedError("dropout in this backbone is not supported by the HIP engine (supported: the actor backbone of IQLPolicy, "
+                                  "which is the one run_iql.py --dropout_rate builds)")
     return lins[0].in_features, [l.out_features for l in lins]
 
 
@@ -337,10 +340,11 @@ class EnginePolicy(BasePolicy):
         P = self._stacked_net(_engine.NET_ACTOR)
         with torch.no_grad():
             h = torch.as_tensor(x, device=self._arena.device)
-            i = 0
-            while f"backbone.model.{2 * i}.weight" in P:
-                h = torch.relu(torch.baddbmm(P[f"backbone.model.{2 * i}.bias"].unsqueeze(1), h, P[f"backbone.model.{2 * i}.weight"].transpose(1, 2)))
-                i += 1
+            # Linear layers of the backbone in nn.Sequential order (indices 0, 2, 4, ... or 0, 3, 6, ... with Dropout layers: evaluation
+            # runs in eval mode, where nn.Dropout is the identity)
+            idx = sorted(int(k[len("backbone.model."):-len(".weight")]) for k in P if k.startswith("backbone.model.") and k.endswith(".weight"))
+            for i in idx:
+                h = torch.relu(torch.baddbmm(P[f"backbone.model.{i}.bias"].unsqueeze(1), h, P[f"backbone.model.{i}.weight"].transpose(1, 2)))
             return self._mode_from_hidden(h, P).cpu().numpy()
 
     def _unbind(self):

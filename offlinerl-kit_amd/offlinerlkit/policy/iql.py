@@ -41,7 +41,10 @@ class IQLPolicy(EnginePolicy):
         return [self.actor_optim, self.critic_q1_optim, self.critic_q2_optim, self.critic_v_optim]
 
     def _config(self) -> Dict:
-        od, hid = _backbone_dims(self.actor.backbone)
+        od, hid = _backbone_dims(self.actor.backbone, allow_dropout=True)
+        p_drop = getattr(self.actor.backbone, "dropout_rate", None)
+        if p_drop is not None and not 0.0 < float(p_drop) < 1.0:
+            raise ValueError(f"dropout_rate must be in (0, 1), got {p_drop}")
         ad = self.actor.dist_net.mu.out_features
         dn = self.actor.dist_net
         if getattr(dn, "_c_sigma", True) or dn._unbounded or float(dn._max) != 1.0:
@@ -53,7 +56,7 @@ class IQLPolicy(EnginePolicy):
         return dict(obs_dim=od, act_dim=ad, hidden=hid, gamma=self._gamma, tau=self._tau,
                     actor_lr=float(self.actor_optim.param_groups[0]["lr"]), critic_lr=float(self.critic_q1_optim.param_groups[0]["lr"]),
                     critic_v_lr=float(self.critic_v_optim.param_groups[0]["lr"]), expectile=self._expectile,
-                    iql_temperature=self._temperature)
+                    iql_temperature=self._temperature, actor_dropout=float(p_drop or 0.0))
 
     def _mode_from_hidden(self, h, P):
         mu = torch.tanh(torch.baddbmm(P["dist_net.mu.bias"].unsqueeze(1), h, P["dist_net.mu.weight"].transpose(1, 2)))    # max_mu = 1 (checked in _config)

@@ -2,7 +2,9 @@
 
 Nets: actor = ActorProb(MLP, DiagGaussian(unbounded=False, conditioned_sigma=False))
 (dist_module.py:45-78: mu = tanh(Linear), sigma = exp(sigma_param (A,1))), critic_q1/q2 (obs+act -> 1),
-critic_v (obs -> 1), targets critic_q1_old / critic_q2_old.  No RNG draws in learn().
+critic_v (obs -> 1), targets critic_q1_old / critic_q2_old.  No RNG draws in learn() -- unless the ACTOR backbone was built with
+``dropout_rate`` (run_iql.py:34,106: only the actor backbone gets it): then the actor forward of the policy-improvement step (iql.py:127, the
+policy is in train() mode) draws one keep mask per hidden layer, ``noise["drop_actor"]`` (cfg["actor_dropout"] = p).
 """
 from __future__ import annotations
 
@@ -25,9 +27,9 @@ def init_opt(state: dict) -> None:
     state["opt"] = {k: nn.adam_init(None) for k in ("actor", "critic_q1", "critic_q2", "critic_v")}
 
 
-def gauss_actor_fwd(net, obs):
+def gauss_actor_fwd(net, obs, drop=None):
     Ws, bs = nn.backbone_layers(net)
-    hs = nn.mlp_fwd(obs, Ws, bs)
+    hs = nn.mlp_fwd(obs, Ws, bs, drop)
     m_raw = nn.mm(hs[-1], net["dist_net.mu.weight"].T) + net["dist_net.mu.bias"]
     mu = np.tanh(m_raw)                                   # max_mu = 1.0 (dist_module.py:70-71)
     ls = net["dist_net.sigma_param"].reshape(1, -1)       # (1, A)   (:75-77)
@@ -77,7 +79,8 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise=None):
     # ---- actor (iql.py:118-131): advantage-weighted BC ----
     v2, _ = nn.critic_fwd(vn, obs)                        # updated V; q_old unchanged (targets not yet synced)
     exp_a = np.minimum(np.exp((q - v2) * f32(cfg["temperature"])), f32(100.0)).astype(f32)
-    mu, sigma, hs = gauss_actor_fwd(actor, obs)
+    p_drop = cfg.get("actor_dropout") or None
+    mu, sigma, hs = gauss_actor_fwd(actor, obs, (p_drop, noise["drop_actor"]) if p_drop else None)
     var = sigma * sigma
     lp = -((act - mu) ** 2) / (f32(2) * var) - np.log(sigma) - nn.LOG_SQRT_2PI
     logp = lp.sum(axis=1, keepdims=True, dtype=f32)
@@ -92,10 +95,10 @@ def learn(state: dict, cfg: dict, batch: Dict[str, np.ndarray], noise=None):
     grads["dist_net.mu.bias"] = dm_raw.sum(axis=0, dtype=f32)
     dh = nn.mm(dm_raw, actor["dist_net.mu.weight"])
     Ws, _ = nn.backbone_layers(actor)
-    dWs, dbs, _ = nn.mlp_bwd(hs, Ws, dh, need_dx=False)
-    for l, (dW, db) in enumerate(zip(dWs, dbs)):
-        grads[f"backbone.model.{2 * l}.weight"] = dW
-        grads[f"backbone.model.{2 * l}.bias"] = db
+    dWs, dbs, _ = nn.mlp_bwd(hs, Ws, dh, need_dx=False, drop_p=p_drop)
+    for i, dW, db in zip(nn.backbone_indices(actor), dWs, dbs):
+        grads[f"backbone.model.{i}.weight"] = dW
+        grads[f"backbone.model.{i}.bias"] = db
     nn.adam_step(actor, grads, state["opt"]["actor"], cfg["actor_lr"])
     aux["exp_a"], aux["logp"] = exp_a, logp
     aux["actor_grads"] = grads

@@ -64,35 +64,42 @@ def mm(a: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 def backbone_layers(net: Dict[str, np.ndarray], prefix: str = "backbone.model.") -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """Collect (W, b) of the Linear layers of an MLP backbone in order.
-    nn.Sequential indices are 0,2,4,... (Linear, ReLU alternating)."""
-    Ws, bs = [], []
-    i = 0
-    while f"{prefix}{i}.weight" in net:
-        Ws.append(net[f"{prefix}{i}.weight"])
-        bs.append(net[f"{prefix}{i}.bias"])
-        i += 2
-    return Ws, bs
+    nn.Sequential indices are 0,2,4,... (Linear, ReLU alternating), or 0,3,6,... when every ReLU is followed by nn.Dropout
+    (nets/mlp.py:20-23)."""
+    idx = sorted(int(k[len(prefix):-len(".weight")]) for k in net if k.startswith(prefix) and k.endswith(".weight"))
+    return [net[f"{prefix}{i}.weight"] for i in idx], [net[f"{prefix}{i}.bias"] for i in idx]
 
 
-def mlp_fwd(x: np.ndarray, Ws: Sequence[np.ndarray], bs: Sequence[np.ndarray]) -> List[np.ndarray]:
-    """Returns [x, h1, ..., hL] with h_l = relu(h_{l-1} W_l^T + b_l)."""
+def backbone_indices(net: Dict[str, np.ndarray], prefix: str = "backbone.model.") -> List[int]:
+    return sorted(int(k[len(prefix):-len(".weight")]) for k in net if k.startswith(prefix) and k.endswith(".weight"))
+
+
+def mlp_fwd(x: np.ndarray, Ws: Sequence[np.ndarray], bs: Sequence[np.ndarray], drop=None) -> List[np.ndarray]:
+    """Returns [x, h1, ..., hL] with h_l = relu(h_{l-1} W_l^T + b_l).
+    drop = (p, [keep mask per layer]): nn.Dropout(p) in training mode behind every ReLU (nets/mlp.py:20-23): h_l *= mask_l / (1 - p)."""
     hs = [np.asarray(x, dtype=f32)]
-    for W, b in zip(Ws, bs):
+    for l, (W, b) in enumerate(zip(Ws, bs)):
         z = mm(hs[-1], W.T) + b
-        hs.append(np.maximum(z, f32(0)))
+        h = np.maximum(z, f32(0))
+        if drop is not None:
+            h = (h * (np.asarray(drop[1][l], f32) / f32(1.0 - drop[0]))).astype(f32)      # ATen: input * (bernoulli(1 - p) / (1 - p))
+        hs.append(h)
     return hs
 
 
 def mlp_bwd(hs: Sequence[np.ndarray], Ws: Sequence[np.ndarray], dh: np.ndarray,
-            need_dx: bool, need_dw: bool = True):
+            need_dx: bool, need_dw: bool = True, drop_p=None):
     """Backward through the backbone.  dh = dLoss/dh_L.
-    ReLU gradient is 1[h > 0] (threshold_backward, strict)."""
+    ReLU gradient is 1[h > 0] (threshold_backward, strict).  drop_p: the forward ran with nn.Dropout(p): hs[l] is the dropped activation, so
+    1[hs > 0] = ReLU mask AND keep mask, and the gradient carries the forward's 1 / (1 - p)."""
     L = len(Ws)
     dWs: List[np.ndarray] = [None] * L
     dbs: List[np.ndarray] = [None] * L
     dx = None
     for l in reversed(range(L)):
         dz = dh * (hs[l + 1] > 0)
+        if drop_p is not None:
+            dz = (dz * (f32(1) / f32(1.0 - drop_p))).astype(f32)
         if need_dw:
             dWs[l] = mm(dz.T, hs[l])
             dbs[l] = dz.sum(axis=0, dtype=f32)

@@ -225,11 +225,13 @@ def gen_cql(ref, case):
 def gen_iql(ref, case):
     sys.path.insert(0, os.path.join(HERE, "..", ".."))
     from oracle import iql as oiql
-    c, st, batches, _ = synth.iql_case_inputs(case)
+    c, st, batches, noises = synth.iql_case_inputs(case)
     cfg = oiql.default_cfg(c["obs_dim"], c["act_dim"])
     cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
-    actor = ref.ActorProb(ref.MLP(od, hid), ref.DiagGaussian(hid[-1], ad, unbounded=False, conditioned_sigma=False))
+    p_drop = cfg.get("actor_dropout")
+    # run_iql.py:106: only the actor backbone is built with dropout_rate
+    actor = ref.ActorProb(ref.MLP(od, hid, dropout_rate=p_drop), ref.DiagGaussian(hid[-1], ad, unbounded=False, conditioned_sigma=False))
     q1, q2, v = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od, hid))
     _load(actor, st["actor"]); _load(q1, st["critic_q1"]); _load(q2, st["critic_q2"]); _load(v, st["critic_v"])
     pol = ref.IQLPolicy(actor, q1, q2, v, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
@@ -240,9 +242,24 @@ def gen_iql(ref, case):
     pol.train()
     rq1, rv = CallRecorder(pol.critic_q1), CallRecorder(pol.critic_v)
     out = OrderedDict(); full = "tiny" in case; keys = None
+    # teacher-forced dropout: nn.Dropout.forward calls torch.nn.functional.dropout; the queued keep masks replace its Bernoulli draws with
+    # ATen's own arithmetic (input * (mask / (1 - p)))
+    drop_q = []
+    orig_dropout = torch.nn.functional.dropout
+
+    def fed_dropout(input, p=0.5, training=True, inplace=False):
+        if not training:
+            return input
+        m = drop_q.pop(0)
+        assert tuple(m.shape) == tuple(input.shape), (m.shape, tuple(input.shape))
+        return input * (torch.tensor(m, dtype=input.dtype) / (1.0 - p))
+    torch.nn.functional.dropout = fed_dropout
     for k, b in enumerate(batches):
         rq1.outs.clear(); rv.outs.clear()
+        if p_drop:
+            drop_q[:] = list(noises[k]["drop_actor"])
         res = pol.learn(_tb(b))
+        assert not drop_q
         keys = keys or list(res.keys())
         out[f"step{k}/losses"] = np.array([res[x] for x in keys], dtype=np.float64)
         if k == 0:
@@ -253,6 +270,7 @@ def gen_iql(ref, case):
             for nm, mod in (("actor", pol.actor), ("critic_q1", pol.critic_q1), ("critic_q2", pol.critic_q2), ("critic_v", pol.critic_v),
                             ("critic_q1_old", pol.critic_q1_old), ("critic_q2_old", pol.critic_q2_old)):
                 _put_state(out, f"state{k}/{nm}", _state_of(mod), full)
+    torch.nn.functional.dropout = orig_dropout
     out["loss_keys"] = np.array(keys)
     return out
 

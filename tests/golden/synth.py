@@ -19,14 +19,14 @@ def _uniform(rng, shape, bound):
     return rng.uniform(-bound, bound, size=shape).astype(f32)
 
 
-def make_backbone(rng, in_dim, hidden, prefix="backbone.model."):
-    """nn.Linear default init magnitude: W,b ~ U(+-1/sqrt(fan_in))."""
+def make_backbone(rng, in_dim, hidden, prefix="backbone.model.", seq_step=2):
+    """nn.Linear default init magnitude: W,b ~ U(+-1/sqrt(fan_in)).  seq_step = 3: an MLP built with dropout_rate ([Linear, ReLU, Dropout])."""
     p = OrderedDict()
     d = in_dim
     for l, h in enumerate(hidden):
         bound = 1.0 / np.sqrt(d)
-        p[f"{prefix}{2 * l}.weight"] = _uniform(rng, (h, d), bound)
-        p[f"{prefix}{2 * l}.bias"] = _uniform(rng, (h,), bound)
+        p[f"{prefix}{seq_step * l}.weight"] = _uniform(rng, (h, d), bound)
+        p[f"{prefix}{seq_step * l}.bias"] = _uniform(rng, (h,), bound)
         d = h
     return p, d
 
@@ -50,9 +50,9 @@ def make_tanh_actor(rng, obs_dim, act_dim, hidden):
     return p
 
 
-def make_gauss_actor(rng, obs_dim, act_dim, hidden):
+def make_gauss_actor(rng, obs_dim, act_dim, hidden, dropout=False):
     """IQL actor: ActorProb(MLP, DiagGaussian(unbounded=False, conditioned_sigma=False))."""
-    p, d = make_backbone(rng, obs_dim, hidden)
+    p, d = make_backbone(rng, obs_dim, hidden, seq_step=3 if dropout else 2)
     bound = 1.0 / np.sqrt(d)
     p["dist_net.sigma_param"] = _uniform(rng, (act_dim, 1), 0.2)
     p["dist_net.mu.weight"] = _uniform(rng, (act_dim, d), bound)
@@ -214,6 +214,9 @@ IQL_CASES = {
     "iql_tiny": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=5, seed=201, over={}),
     "iql_tiny_h3": dict(obs_dim=4, act_dim=2, hidden=[32, 32, 32], B=8, steps=3, seed=202, over=dict(expectile=0.9, temperature=1.0)),
     "iql_hopper": dict(obs_dim=11, act_dim=3, hidden=[256, 256], B=256, steps=20, seed=21, over={}),
+    # run_iql.py --dropout_rate: nn.Dropout behind every ReLU of the ACTOR backbone (run_iql.py:106), keep masks teacher-forced
+    "iql_tiny_dropout": dict(obs_dim=5, act_dim=3, hidden=[32, 32], B=16, steps=4, seed=203, over=dict(actor_dropout=0.25)),
+    "iql_hopper_dropout": dict(obs_dim=11, act_dim=3, hidden=[256, 256], B=256, steps=3, seed=22, over=dict(actor_dropout=0.1)),
 }
 
 TD3BC_CASES = {
@@ -232,14 +235,18 @@ def iql_case_inputs(case):
     rng = np.random.RandomState(c["seed"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
     st = OrderedDict()
-    st["actor"] = make_gauss_actor(rng, od, ad, hid)
+    p_drop = c["over"].get("actor_dropout")
+    st["actor"] = make_gauss_actor(rng, od, ad, hid, dropout=bool(p_drop))
     st["critic_q1"] = make_critic(rng, od + ad, hid)
     st["critic_q2"] = make_critic(rng, od + ad, hid)
     st["critic_v"] = make_critic(rng, od, hid)
     st["critic_q1_old"] = _perturbed(rng, st["critic_q1"])
     st["critic_q2_old"] = _perturbed(rng, st["critic_q2"])
     batches = [make_batch(rng, c["B"], od, ad) for _ in range(c["steps"])]
-    return c, st, batches, [None] * c["steps"]
+    if not p_drop:
+        return c, st, batches, [None] * c["steps"]
+    noises = [OrderedDict(drop_actor=[(rng.uniform(size=(c["B"], h)) < 1.0 - p_drop).astype(f32) for h in hid]) for _ in range(c["steps"])]
+    return c, st, batches, noises
 
 
 def td3bc_case_inputs(case):

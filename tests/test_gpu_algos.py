@@ -25,7 +25,7 @@ def make_engine(algo, case, n_runs=1, precision=0):
     c = getattr(synth, f"{algo.upper()}_CASES")[case]
     over = dict(obs_dim=c["obs_dim"], act_dim=c["act_dim"], hidden=c["hidden"], batch_size=c["B"], n_runs=n_runs, precision=precision)
     if algo == "iql":
-        over.update(expectile=cfg["expectile"], iql_temperature=cfg["temperature"])
+        over.update(expectile=cfg["expectile"], iql_temperature=cfg["temperature"], actor_dropout=float(cfg.get("actor_dropout") or 0.0))
     elif algo == "td3bc":
         over.update(update_actor_freq=cfg["update_actor_freq"], td3bc_alpha=cfg["alpha"])
     elif algo == "edac":
@@ -50,7 +50,7 @@ def lead(d):
 
 def noise_list(algo, n):
     if algo == "iql":
-        return None
+        return list(n["drop_actor"]) if n is not None else None      # keep masks of the actor backbone's dropout layers (run_iql.py --dropout_rate)
     if algo == "td3bc":
         return [n["eps_target"]]
     return [n["eps_actor"], n["eps_next"]]

@@ -414,3 +414,54 @@ def test_reference_pinned_dataset_through_load_dataset_into_hbm_and_back(case):
     # the device store holds exactly the reference's transitions: every row once, through the C ABI gather with idx = 0 .. n - 1
     dev = buf.device_buffer()
     assert dev.size() == n
+
+
+def test_iql_policy_with_actor_dropout_matches_reference_fixture():
+    """run_iql.py --dropout_rate: nn.Dropout behind every ReLU of the ACTOR backbone (nets/mlp.py:16-24, run_iql.py:106).  The policy is
+    built from our MLP(dropout_rate=p) exactly as the launcher builds it; the keep masks of the reference's draws are teacher-forced; losses
+    follow the fixture captured from the REAL reference (tests/golden/iql_tiny_dropout.npz) and the oracle at the 1e-4 gate, state_dict keys
+    are the reference's (backbone.model.{0, 3}), evaluation runs without dropout, and a critic backbone with dropout is refused."""
+    from helpers import load_golden
+    from offlinerlkit.modules import ActorProb, Critic, DiagGaussian
+    from offlinerlkit.nets import MLP
+    from offlinerlkit.policy import IQLPolicy
+    case = "iql_tiny_dropout"
+    mod, cfg, st, batches, noises = generic_oracle_setup("iql", case)
+    c = synth.IQL_CASES[case]
+    od, ad, hid, p = c["obs_dim"], c["act_dim"], c["hidden"], cfg["actor_dropout"]
+    g = load_golden(case)
+
+    def build(critic_dropout=None):
+        actor = ActorProb(MLP(od, hid, dropout_rate=p), DiagGaussian(hid[-1], ad, unbounded=False, conditioned_sigma=False), DEV)
+        q1, q2, v = Critic(MLP(od + ad, hid, dropout_rate=critic_dropout), DEV), Critic(MLP(od + ad, hid), DEV), Critic(MLP(od, hid), DEV)
+        load(actor, st["actor"]); load(q2, st["critic_q2"]); load(v, st["critic_v"])
+        if critic_dropout is None:
+            load(q1, st["critic_q1"])
+        adam = lambda m, lr: torch.optim.Adam(m.parameters(), lr=lr)
+        return IQLPolicy(actor, q1, q2, v, adam(actor, cfg["actor_lr"]), adam(q1, cfg["critic_q_lr"]), adam(q2, cfg["critic_q_lr"]),
+                         adam(v, cfg["critic_v_lr"]), action_space=Space(ad), tau=cfg["tau"], gamma=cfg["gamma"], expectile=cfg["expectile"],
+                         temperature=cfg["temperature"])
+    pol = build()
+    load(pol.critic_q1_old, st["critic_q1_old"]); load(pol.critic_q2_old, st["critic_q2_old"])
+    assert "actor.backbone.model.3.weight" in pol.state_dict() and "actor.backbone.model.2.weight" not in pol.state_dict()
+    pol.train()
+    for k, (b, n) in enumerate(zip(batches, noises)):
+        res, _ = mod.learn(st, cfg, b, n)
+        out = pol.learn(tb(b), noise=list(n["drop_actor"]))
+        got = np.array([out[x] for x in res])
+        assert rel_err(got, np.array(list(res.values())), floor=1e-2) < 1e-4, (k, out, res)
+        assert rel_err(got, g[f"step{k}/losses"], floor=1e-2) < 1e-4, (k, out, g[f"step{k}/losses"])
+    state_close(pol, st, ("actor", "critic_q1", "critic_q2", "critic_v"), 3e-6)
+    # device-drawn masks: finite, and the keep rate is 1 - p
+    out = pol.learn(tb(batches[0]))
+    assert np.isfinite(list(out.values())).all()
+    keep = pol.engine.debug_read(0, "n_drop_a0")
+    assert set(np.unique(keep)) <= {0.0, 1.0} and abs(keep.mean() - (1 - p)) < 0.08
+    pol.eval()
+    a1 = pol.select_action(batches[0]["observations"], deterministic=True)
+    a2 = pol.select_action(batches[0]["observations"], deterministic=True)
+    assert np.array_equal(a1, a2)                                   # eval mode: nn.Dropout is the identity
+    assert np.allclose(pol.select_action_runs(batches[0]["observations"][None])[0], a1, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        bad = build(critic_dropout=0.1)
+        bad.learn(tb(batches[0]))
