@@ -16,8 +16,11 @@ all_gather of the per-run metric means at the end, as MFPolicyTrainer would log 
 
 The timed block of K steps (barrier + synchronize on both sides, max over ranks) is repeated (>= 5 blocks and
 >= 2 s, --min-reps / --min-seconds); `value` is the median block, every block is listed in `reps`.
-Side records of the same run (rank 0, N = 1 only): `fp32` (exact-fp32 MFMA, same workload), `by_runs` (runs per
-GPU 1 .. 192), `other_configs` (BASELINE configs 3 and 4), `roofline`, `cpu_baseline`.
+Side records of the same run (rank 0, N = 1 only): `value_fp32` / `fp32` (exact-fp32 MFMA, same workload), `target`
+(both over the north_star's 50k), `by_runs` (runs per GPU 1 .. 192), `other_configs` (TD3BC, IQL = BASELINE configs[2], EDAC =
+configs[3]; 128 runs each), `api` (a fused MFPolicyTrainer epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer),
+`roofline` (+ `traffic_source`), `cpu_baseline`.  `--rccl-check` opens a world-size-1 nccl group and runs the path's collectives
+on device tensors (tests/test_gpu_rccl.py).  Workload construction shared with the tools lives in bench_workloads.py.
 """
 from __future__ import annotations
 
