@@ -191,6 +191,10 @@ struct Engine {
   void prof_end();
   int assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep);
   int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
+  // a pass nobody differentiates (target nets, the actor's action proposals for the critic loss): the weight-stationary launches keep
+  // hidden activations they do not need themselves out of HBM (they are marked dead: a later reader fails loudly)
+  int mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
+  bool fwd_only = false;       // set while mlp_forward_only enqueues
   // the same with nn.Dropout(p) behind every hidden ReLU (keep masks in `masks[i]`, [R][M][H_i]); layer by layer on the tiled kernels
   int mlp_forward_dropout(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag, float p,
                           const std::vector<Mat>& masks);

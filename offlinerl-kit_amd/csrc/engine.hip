@@ -311,7 +311,7 @@ static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag,
   const double flops = 2.0 * p.M * (double)p.N * p.K * nz;
   // algorithmic bytes: each operand read once, the result written once (split-K: one slab per split), mask read once
   const double bytes = 4.0 * nz * ((double)p.M * p.K + (double)p.N * p.K + (double)p.M * p.N * (EPI == E_WGRAD ? p.ksplit : 1) +
-                                   (EPI == E_MASK ? (double)p.M * p.N : 0.0));
+                                   (EPI == E_MASK ? (double)p.M * p.N / (p.aux_bits ? 32.0 : 1.0) : 0.0));
   double bytes_adj = bytes;
   if (EPI == E_MASK && p.w0_out) bytes_adj += 4.0 * nz * ((double)p.M * p.w0_xsr - (p.C ? 0.0 : (double)p.M * p.N));
   e->prof_begin(tag, flops + (EPI == E_MASK && p.w0_out ? 2.0 * p.M * (double)p.N * (p.w0_in + 1) * nz : 0.0), bytes_adj);
@@ -351,7 +351,13 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   p.nz1 = nr.nz1; p.ksplit = 1;
   vals_dead.erase(Y.p);
   p.bias = {nr.base + l.b_off[layer], nr.rs, l.b_ms[layer]};
-  if (maskH) { p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch; }
+  if (maskH) {
+    p.aux = {maskH->p, maskH->rs, maskH->cs}; p.aux_sr = maskH->pitch;
+    // the ReLU mask as packed bits (1/32 of the bytes) when the forward pass that produced the activation left them behind
+    if (epi == E_MASK && maskH->bits && bits_live.count(maskH->bits) && out == maskH->pitch && aligned16(maskH->p) && (maskH->pitch & 3) == 0) {
+      p.aux_bits = maskH->bits; p.xb_s0 = maskH->brs; p.xb_s1 = maskH->bcs; p.xb_g = maskH->bg;
+    }
+  }
   const int nz = R * nr.nz1;
   int cfg = pick_cfg(p.M, p.N, p.K, nz);
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
@@ -375,7 +381,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     }
     // With the single-output tail folded in, the backward pass of a many-row batch needs only the mask bits of this activation
     // (ws_dgrad_w0 / ws_wgrad's derived tail gradients): the activation itself then never goes to HBM.
-    const bool elide = want_tail && elide_top && !l.ens && layer >= 1 && (long)M * nz >= ws_wgrad_min_rows;
+    const bool elide = want_tail && layer >= 1 && (fwd_only || (elide_top && !l.ens && (long)M * nz >= ws_wgrad_min_rows));
     if (elide) w.Y = nullptr;
     const bool ws_ok = ws_fwd_supported(w, in, out);
     bool fused0 = false;
@@ -387,6 +393,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       w.mb0 = X.bits; w.mb0_s0 = X.brs; w.mb0_s1 = X.bcs; w.mb0_g = X.bg;
       fused0 = ws_fwd01_supported(w) && aligned16(fuse_X0->p);
       if (!fused0) w.X0 = nullptr;
+      else if (fwd_only) w.x0_discard = 1;
     }
     if (fuse_X0 && !fused0) {      // layer 0 on its own, then this layer
       if (linear_fwd(*fuse_X0, M, nr, 0, X, E_BIAS_RELU, nullptr, tag0 ? tag0 : tag)) return -1;
@@ -395,8 +402,11 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     if (ws_ok) {
       const double f0 = fused0 ? 2.0 * M * (double)in * (w.in0 + 1) * nz : 0.0;
       prof_begin(tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
-                 4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (double)M * in + (double)out * in + (elide ? (double)M * out / 32 : (double)M * out)));
+                 4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (w.x0_discard ? (double)M * in / 32 : (double)M * in) + (double)out * in +
+                             (elide ? (double)M * out / 32 : (double)M * out)));
       if (fused0) bits_live.insert(X.bits);
+      if (w.x0_discard) vals_dead.insert(X.p);
+      else if (fused0) vals_dead.erase(X.p);
       hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
@@ -741,6 +751,12 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   }
   if (tail_done) return 0;                 // single-output tail folded into the last hidden layer's epilogue
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
+}
+
+int Engine::mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag) {
+  struct Scope { Engine* e; ~Scope() { e->fwd_only = false; } } scope{this};
+  fwd_only = true;
+  return mlp_forward(X, M, nr, hs, out, tag);
 }
 
 int Engine::scale_inplace(const Mat& m, int rows, int cols, int nets, float s, const Mat* mask, const char* tag) {

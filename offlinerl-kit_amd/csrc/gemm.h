@@ -247,7 +247,12 @@ static inline int pick_cfg(int M, int N, int K, int nz) {
   // batch-sized products of MANY batched nets (e.g. the 256-row phases of 64+ runs): enough 128 x 128 / 64 x 64 tiles exist to fill the
   // CUs, and they re-read each operand far less often than the 16 x 64 tiles (256 x 256 x 256, 128 nets: wgrad 108 -> 42 us with two
   // k-ranges, forward 68 -> 38 us, dgrad 96 -> 47 us; tools/small_gemm_sweep.py)
+  // narrow products of many nets (the first layer's weight gradient, 17 .. 63 inputs): 64-row tiles read 256-byte pieces of the
+  // transposed operand's rows where the 16-row tiles read 64-byte ones
+  if (K < 1024 && M >= 64 && N > 16 && N < 64 && (long)nz * ((M + 63) / 64) >= 1024) return CFG_MID;
   if (K < 1024 && M >= 64 && N >= 64) {
+    // a few input columns only (EDAC's t_0 = (gamma W_0[action rows]) (.) m_0): the launch is its epilogue -- 128 x 128 tiles move 64 KB each
+    if (K <= 32 && M >= 128 && N >= 128 && (long)nz * ((M + 127) / 128) * ((N + 127) / 128) >= 1024) return CFG_SQ;
     if (K >= 256 && M >= 128 && N >= 128 && (long)nz * ((M + 127) / 128) * ((N + 127) / 128) >= 256) return CFG_SQ;
     if ((long)nz * ((M + 63) / 64) * ((N + 63) / 64) >= 1024) return CFG_MID;
   }

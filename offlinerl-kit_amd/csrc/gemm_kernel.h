@@ -435,7 +435,30 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   constexpr bool LDS_EPI_FITS = (size_t)TM * CP * sizeof(float) <= CFG::epi_lds_limit(PREC) && (NT % (TN / 4)) == 0;
   constexpr bool W0_CAP = (EPI == E_MASK) && (TN / (NT / 64) == 32) && (TM % 16 == 0);
   const bool w0 = W0_CAP && (p.w0_out != nullptr);             // uniform; the host only asks when the LDS path below is taken
-  if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
+  // Weight gradients stored (in, out)-major (EnsembleLinear: c_sr == 1, consecutive m are consecutive in memory): stage the tile
+  // TRANSPOSED and store whole m-runs, instead of 64-byte pieces of 16 different rows per instruction in the direct path.
+  constexpr bool TR_CAP = (EPI == E_WGRAD) && (TM == TN) && LDS_EPI_FITS && (NT % (TM / 4)) == 0;
+  const bool tr_ok = TR_CAP && p.c_sr == 1 && p.c_sn != 1 && (p.c_sn & 3) == 0 && (p.c_s0 & 3) == 0 && (p.c_s1 & 3) == 0 && (p.c_ks & 3) == 0 &&
+                     ((((uintptr_t)p.C) & 15) == 0) && (p.M & 3) == 0;                    // uniform per launch
+  if (TR_CAP && tr_ok) {
+    float* cs = smem;
+    if (PA == PA_RANK1 && LA == L_BLK4) __syncthreads();      // the tail-gradient reduction above used smem
+#pragma unroll
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[(wcol0 + b * 16 + 4 * lq + j) * CP + wrow0 + a * 16 + li] = acc[a][b][j];
+    __syncthreads();
+    constexpr int C4 = TM / 4, RPP = NT / C4, NPASS = (TN + RPP - 1) / RPP;   // float4 pieces per n-row, n-rows per pass
+    const int c4 = tid % C4, r0 = tid / C4;
+    const int m = m0 + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+      const int r = r0 + i * RPP, n = n0 + r;
+      if (r < TN && n < p.N && m < p.M) *(f32x4*)&Cg[(long)n * p.c_sn + m] = *(const f32x4*)&cs[r * CP + 4 * c4];
+    }
+  } else if (LDS_EPI_FITS && (vec_ok || (w0 && p.C == nullptr)) && (p.N & 3) == 0) {             // uniform per workgroup
     float* cs = smem;
     constexpr int C4 = TN / 4, RPP = NT / C4, NPASS = (TM + RPP - 1) / RPP;   // float4 columns per row, rows per pass
     constexpr bool MB_CAP = (C4 % 8) == 0;                                     // eight lanes of a row own one 32-column mask word

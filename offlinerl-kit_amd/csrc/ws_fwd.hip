@@ -7,7 +7,9 @@ namespace orl {
 // way (fp32 [256 x 32] vs bf16 hi + lo), the LDS image holds the fp32 rows themselves ([buf][row][256] floats, 16-byte chunks
 // XOR-swizzled with the row like the bf16 planes), and a lane's ds_read_b128 of four consecutive k feeds four MFMAs (the k order
 // inside a 16-wide step is free as long as the resident weight fragments use the same one).
-template <bool TQ, bool L0, bool DG = false, bool SY = true, bool F32 = false>      // SY = false: the activation itself is not stored (TQ only)
+// SY = false: the activation itself is not stored (TQ only); XS = false (L0 only): the fused first layer's h0 is not stored either
+// (forward-only passes, WsFwdP::x0_discard -- a compile-time flavour: the same test at run time costs the product kernel ~20 %)
+template <bool TQ, bool L0, bool DG = false, bool SY = true, bool F32 = false, bool XS = true>
 __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   hx_t* Ah = (hx_t*)ws_smem;                                   // [buf][plane][row][WS_PITCH]
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     }
     const unsigned int nib0 = orl_relu_mask4(v);
     const int k = ncol0 + 16 * cb + 4 * lq;                      // h0 columns k .. k + 3 of row r (lane holds C[m = li][n = 4 lq + j])
-    *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
+    if constexpr (XS) *(f32x4*)&Y0g[m * p.x_pitch + k] = v;
     if constexpr (F32) {
       *(f32x4*)(Af + (long)buf * WS_ROWS * WS_K + r * WS_K + (((k >> 2) ^ (r & 15)) << 2)) = v;
     } else {
@@ -446,6 +448,8 @@ static hipError_t ws_fwd_attrs() {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, false, true, true, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, false, false, false, F32>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<true, true, false, false, F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd_kernel<false, true, false, true, F32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
   return e;
 }
 
@@ -453,7 +457,10 @@ template <bool F32>
 static void ws_fwd_dispatch(const WsFwdP& p, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   const bool l0 = p.X0 != nullptr;
   if (p.dmask) hipLaunchKernelGGL((ws_fwd_kernel<false, false, true, true, F32>), grid, block, lds, st, p);
-  else if (l0) {
+  else if (l0 && p.x0_discard && !(p.tq && p.Y)) {     // forward-only passes (storing h0 anyway is always correct: any other shape takes the storing flavour)
+    if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false, F32, false>), grid, block, lds, st, p);
+    else hipLaunchKernelGGL((ws_fwd_kernel<false, true, false, true, F32, false>), grid, block, lds, st, p);
+  } else if (l0) {
     if (p.tq && !p.Y) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, false, F32>), grid, block, lds, st, p);
     else if (p.tq) hipLaunchKernelGGL((ws_fwd_kernel<true, true, false, true, F32>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((ws_fwd_kernel<false, true, false, true, F32>), grid, block, lds, st, p);

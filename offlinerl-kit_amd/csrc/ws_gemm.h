@@ -42,6 +42,7 @@ struct WsFwdP {
   // fused first layer (template L0): X is then PRODUCED here as relu(X0 W0^T + b0) from the narrow input rows X0 (in0 + 1 <= 32 columns
   // incl. the bias as a ones column), stored to `X` for the backward pass, and handed to the second layer through LDS only
   const float* X0; long x0_s0, x0_s1; int x0_pitch, in0;
+  int x0_discard;               // fused first layer of a forward-only pass: h0 goes to LDS and its mask bits to HBM, the values are not stored
   const float* W0; long w0_s0, w0_s1, w0_sn, w0_sk;     // element (n, k) at W0[n * w0_sn + k * w0_sk] ((256, in0) row-major: in0, 1)
   const float* b0; long b0_s0, b0_s1;
   unsigned int* mb0; long mb0_s0, mb0_s1; int mb0_g;    // packed ReLU mask of X (= h0)
