@@ -6,6 +6,9 @@
 // MODE 1: reads, wait, then MFMA + 3-4 vector instructions, twelve times (a hand-interleaved stream)
 // MODE 2: as 0, but waves 4-7 (the second wave of every SIMD) run the vector block BEFORE the MFMAs (half a k step out of phase)
 // MODE 3: MFMAs only (the floor);  MODE 4: vector instructions only
+// MODE 5: SPECIALISED waves -- waves 0-3 (one per SIMD) issue all 24 MFMAs of the SIMD's k step (two column halves off the same four fragment
+//         reads) and nothing else; waves 4-7 issue all 2 NV vector instructions.  Same work per SIMD and k step as modes 0-2.
+// MODE 6: as 5, and the vector waves also move the accumulators' worth of data through LDS (8 ds_read_b128 per 8 k steps)
 // NV = vector instructions per k step (default 45), VKIND as in coexec_probe.hip (4 = v_max_f32, half rate).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -29,6 +32,43 @@ __global__ __launch_bounds__(512) void probe(float* out, int groups, float s) {
   float v[8] = {1, 2, 3, 4, 5, 6, 7, 8};
   __syncthreads();
   const bool late = (MODE == 2) && wave >= 4;
+  if (MODE == 5 || MODE == 6) {
+    f32x4 acc2[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int g = 0; g < groups; ++g) {
+      if (wave < 4) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          h8 fa[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) fa[r] = *(const h8*)&img[((r & 1) * 16 + li) * 256 + (((4 * ks + lq + 8 * (r >> 1)) ^ li) << 3)];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 12; ++j) {
+            acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[j & 1], fa[j & 3], acc[j & 3], 0, 0, 0);
+            acc2[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[(j + 1) & 1], fa[j & 3], acc2[j & 3], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+          for (int j = 0; j < 2 * NV; ++j) valu_op(v[j & 7], s);
+          if (MODE == 6) {
+            const f32x4 t = *(const f32x4*)&img[(ks * 64 + lane) * 8];
+            v[ks & 7] += t[0] + t[3];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __syncthreads();
+    }
+    float r = 0.f;
+    for (int i = 0; i < 4; ++i) r += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + acc2[i][0] + acc2[i][3];
+    for (int i = 0; i < 8; ++i) r += v[i];
+    out[blockIdx.x * 512 + tid] = r;
+    return;
+  }
   for (int g = 0; g < groups; ++g) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -96,6 +136,8 @@ int main() {
     run<0>("clustered: 12 MFMAs, then the vector block (compiler's order for the epilogue pieces)", blocks);
     run<1>("interleaved: MFMA + 3-4 vector instructions, twelve times", blocks);
     run<2>("clustered, waves 4-7 run the vector block BEFORE their MFMAs (half a k step out of phase)", blocks);
+    run<5>("specialised: waves 0-3 all MFMAs (24 per k step), waves 4-7 all vector instructions", blocks);
+    run<6>("specialised, vector waves also read 8 x 1 KB from LDS per group", blocks);
   }
   return 0;
 }
