@@ -278,21 +278,32 @@ def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump
                     t["name"], t["launches"] / steps, us, t["total_ms"] / steps * 1e3, 100 * t["total_ms"] / tot,
                     t["flops_per_launch"] / us / 1e6, t["bytes_per_launch"] / us / 1e3))
             f.write("%-40s %9s %10s %10.1f\n" % ("total", "", "", tot / steps * 1e3))
-    gemms = [t for t in table if t["flops_per_launch"] > 0]
-    if not gemms:
+    modelled = [t for t in table if t["flops_per_launch"] > 0 or t["bytes_per_launch"] > 0]
+    if not modelled:
         return None
-    top = max(gemms, key=lambda t: t["total_ms"])
+    # the dominant launch = the tag with the most time; the roof that binds it = the one it is closer to (a launch at 0.56 of HBM and 0.17
+    # of the MFMA ceiling is HBM-bound; Adam has no matrix work at all)
+    top = max(modelled, key=lambda t: t["total_ms"])
     avg_ms = top["total_ms"] / top["launches"]
     ach = top["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
     peak = PEAK_TFLOPS[precision]
     gbps = top["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
     traffic, traffic_source = pmc_traffic(top["name"], R, precision)
-    roof = dict(bound="mfma", kernel=top["name"], achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+    mfma = dict(flops_per_launch=top["flops_per_launch"], achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
+    # the same launch against the HBM roof (algorithmic bytes: operands read once, result written once)
+    hbm = dict(bytes_per_launch=top["bytes_per_launch"], achieved=gbps, peak=8000.0, unit="GB/s", frac=gbps / 8000.0)
+    by_hbm = hbm["frac"] > mfma["frac"]
+    roof = dict(bound="hbm" if by_hbm else "mfma", kernel=top["name"], achieved=gbps if by_hbm else ach, peak=8000.0 if by_hbm else peak,
+                unit="GB/s" if by_hbm else "TFLOP/s", frac=hbm["frac"] if by_hbm else mfma["frac"],
                 traffic=traffic, traffic_source=traffic_source, avg_launch_ms=avg_ms, avg_launch_from="eager launches of engine 0 alone, HIP events on its stream",
-                flops_per_launch=top["flops_per_launch"],
-                # the same launch against the HBM roof (algorithmic bytes: operands read once, result written once)
-                hbm=dict(bytes_per_launch=top["bytes_per_launch"], achieved=gbps, peak=8000.0, unit="GB/s", frac=gbps / 8000.0),
+                flops_per_launch=top["flops_per_launch"], hbm=hbm, mfma=mfma,
                 table=[dict(name=t["name"], ms_per_step=t["total_ms"] / steps, launches_per_step=t["launches"] / steps) for t in table[:12]])
+    gemms = [t for t in table if t["flops_per_launch"] > 0]
+    if gemms and by_hbm:                      # the matrix launch that takes the most time, for reference
+        g = max(gemms, key=lambda t: t["total_ms"])
+        g_ms = g["total_ms"] / g["launches"]
+        roof["dominant_gemm"] = dict(kernel=g["name"], avg_launch_ms=g_ms, mfma_frac=g["flops_per_launch"] / (g_ms * 1e-3) / 1e12 / peak,
+                                     hbm_frac=g["bytes_per_launch"] / (g_ms * 1e-3) / 1e9 / 8000.0)
     if flops_step is not None and value is not None:
         roof["step_frac_of_mlp_gemm_roofline"] = value * flops_step / (peak * 1e12)
     # the whole step against the HBM roof: algorithmic bytes of every launch (operands read once, results written once) over the eager step time
@@ -300,7 +311,7 @@ def profile_roofline(eng, steps, precision, R, flops_step=None, value=None, dump
     tot_bytes = sum(t["bytes_per_launch"] * t["launches"] for t in table)
     roof["whole_step_hbm"] = dict(algorithmic_gb_per_step=tot_bytes / steps / 1e9, achieved_gbps=tot_bytes / (tot_ms * 1e-3) / 1e9, peak_gbps=8000.0,
                                   frac=tot_bytes / (tot_ms * 1e-3) / 1e9 / 8000.0,
-                                  note="launches without a byte model (Adam, sampling, loss kernels) count as zero bytes: a lower bound")
+                                  note="launches without a byte model (sampling, loss and assembly kernels) count as zero bytes: a lower bound")
     return roof
 
 

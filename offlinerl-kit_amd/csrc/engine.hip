@@ -717,14 +717,23 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
   a.b1 = cfg.adam_beta1; a.b2 = cfg.adam_beta2; a.eps = cfg.adam_eps; a.tau = cfg.tau;
   a.gstep = gstep; a.t_div = t_div;
-  ORL_LAUNCH("adam", k_adam, dim3((unsigned)((l.size + 1023) / 1024), nnets, R), dim3(256), a);    // four parameters per thread
+  // algorithmic bytes: every gradient slab read once, m / v / parameter read and written, the Polyak target read and written
+  double bytes = 0.0;
+  for (int i = 0; i < a.nseg; ++i) bytes += (double)(a.seg_end[i] - (i ? a.seg_end[i - 1] : 0)) * (4.0 * a.seg_nslab[i] + 24.0 + (a.target ? 8.0 : 0.0));
+  prof_begin("adam", 0, bytes * nnets * R);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((l.size + 1023) / 1024), nnets, R), dim3(256), 0, stream, a);    // four parameters per thread
+  prof_end();
+  if (hipGetLastError() != hipSuccess) return fail("adam: launch failed");
   return 0;
 }
 
 int Engine::polyak(int target_net, int src_net, int nnets) {
   const long P = lay[src_net].size, PS = lay[src_net].stride();
-  ORL_LAUNCH("polyak", k_polyak, dim3((unsigned)((P + 255) / 256), nnets, R), dim3(256), net_ptr(0, target_net), P_tgt, PS,
-             (const float*)net_ptr(0, src_net), P_train, PS, P, cfg.tau);
+  prof_begin("polyak", 0, 12.0 * P * nnets * R);
+  hipLaunchKernelGGL(k_polyak, dim3((unsigned)((P + 255) / 256), nnets, R), dim3(256), 0, stream, net_ptr(0, target_net), P_tgt, PS,
+                     (const float*)net_ptr(0, src_net), P_train, PS, P, cfg.tau);
+  prof_end();
+  if (hipGetLastError() != hipSuccess) return fail("polyak: launch failed");
   return 0;
 }
 
@@ -1539,7 +1548,7 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, p.a, p.b) != hipSuccess) continue;
     auto& a = agg[p.name];
-    std::get<0>(a) += ms; std::get<1>(a) += 1; std::get<2>(a) = p.flops; std::get<3>(a) = p.bytes;
+    std::get<0>(a) += ms; std::get<1>(a) += 1; std::get<2>(a) += p.flops; std::get<3>(a) += p.bytes;
   }
   std::vector<std::pair<double, std::string>> order;
   for (auto& kv : agg) order.push_back({-std::get<0>(kv.second), kv.first});
@@ -1547,8 +1556,8 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
   if (idx < 0 || idx >= (int)order.size()) return 1;
   const auto& a = agg[order[idx].second];
   snprintf(name, name_cap, "%s", order[idx].second.c_str());
-  *total_ms = std::get<0>(a); *launches = std::get<1>(a); *flops_per_launch = std::get<2>(a);
-  if (bytes_per_launch) *bytes_per_launch = std::get<3>(a);
+  *total_ms = std::get<0>(a); *launches = std::get<1>(a); *flops_per_launch = std::get<2>(a) / std::get<1>(a);      // means over the tag's launches
+  if (bytes_per_launch) *bytes_per_launch = std::get<3>(a) / std::get<1>(a);
   return 0;
 }
 

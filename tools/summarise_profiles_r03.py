@@ -1,5 +1,6 @@
 """Turn the raw rocprofv3 / HIP-event outputs of tools/collect_profiles_r03.sh (gpurun_out/prof_r03/) into the committed profiles/r03_* files:
-    python tools/summarise_profiles_r03.py [COMMIT]
+    python tools/summarise_profiles_r03.py [COMMIT [SECTIONS]]      SECTIONS: comma list of cql, algos, few (default all) -- the raw directory may
+    hold sections collected at different commits
 kernel stats csv (copied), dispatch classes (each kernel's dispatches split into a long and a short duration class: the many-row and the
 256-row launches of one kernel), PMC traffic summaries (tools/pmc_summary.py corrections), SQ counter tables, few-runs traces, tag tables."""
 import collections
@@ -15,6 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
 DST = os.path.join(ROOT, "profiles")
+SECTIONS = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"cql", "algos", "few"}
 commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 
 
@@ -65,9 +67,10 @@ def run_tool(tool, args, out, header):
 
 
 B = "python3 bench.py --steps 20 --warmup 5 --no-sides --no-cpu-baseline --profile-steps 0 --min-reps 1 --min-seconds 0"
-copy_stats("default_stats", "r03_cql_default_2x96_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B}  (2 engines x 96 runs, split precision; with two engines wall durations of one engine's launches include waiting behind the other's)")
-copy_stats("1x128_stats", "r03_cql_1x128_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B} --engines-per-gpu 1 --runs-per-gpu 128")
-for a in ("iql", "td3bc", "edac"):
+if "cql" in SECTIONS:
+  copy_stats("default_stats", "r03_cql_default_2x96_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B}  (2 engines x 96 runs, split precision; with two engines wall durations of one engine's launches include waiting behind the other's)")
+  copy_stats("1x128_stats", "r03_cql_1x128_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B} --engines-per-gpu 1 --runs-per-gpu 128")
+for a in (("iql", "td3bc", "edac") if "algos" in SECTIONS else ()):
     copy_stats(f"{a}_stats", f"r03_{a}_128runs_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- python3 tools/algo_run.py {a} 128 1 30")
     t = os.path.join(SRC, f"tags_{a}.txt")
     if os.path.exists(t):
@@ -76,13 +79,13 @@ for a in ("iql", "td3bc", "edac"):
         run_tool("pmc_summary.py", [os.path.join(SRC, f"{a}_FETCH_SIZE"), os.path.join(SRC, f"{a}_WRITE_SIZE")], f"r03_pmc_summary_{a}_128runs.md",
                  f"## HBM traffic per launch, {a.upper()} at 128 runs, split precision (commit {commit})\nseparate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `python3 tools/algo_run.py {a} 128 1 30`; gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x 2, counters in KiB)\n\n")
 for t, name in (("tags_1x128.txt", "r03_hip_event_tags_1x128.txt"), ("tags_fp32_1x128.txt", "r03_hip_event_tags_fp32_1x128.txt")):
-    if os.path.exists(os.path.join(SRC, t)):
+    if "cql" in SECTIONS and os.path.exists(os.path.join(SRC, t)):
         shutil.copy(os.path.join(SRC, t), os.path.join(DST, name))
 for b, name in (("bench_1x128.json", "r03_bench_1x128.json"), ("bench_fp32_1x128.json", "r03_bench_fp32_1x128.json")):
-    if os.path.exists(os.path.join(SRC, b)):
+    if "cql" in SECTIONS and os.path.exists(os.path.join(SRC, b)):
         shutil.copy(os.path.join(SRC, b), os.path.join(DST, name))
 # PMC traffic of the dominant kernels, one engine x 96 runs in the one-round decomposition of the two-engine default
-if one("1x96_FETCH_SIZE/**/*counter_collection.csv") and one("1x96_WRITE_SIZE/**/*counter_collection.csv"):
+if "cql" in SECTIONS and one("1x96_FETCH_SIZE/**/*counter_collection.csv") and one("1x96_WRITE_SIZE/**/*counter_collection.csv"):
     txt = run_tool("pmc_summary.py", [os.path.join(SRC, "1x96_FETCH_SIZE"), os.path.join(SRC, "1x96_WRITE_SIZE")], "r03_pmc_summary_1x96_one_round.md",
                    f"## HBM traffic per launch, CQL, one engine x 96 runs, ORL_WS_ONE_ROUND=1 (the decomposition of the two-engine default), split precision (commit {commit})\nseparate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `{B} --engines-per-gpu 1 --runs-per-gpu 96`; gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x 2, counters in KiB)\n\n")
     traffic = {}
@@ -97,14 +100,14 @@ if one("1x96_FETCH_SIZE/**/*counter_collection.csv") and one("1x96_WRITE_SIZE/**
     if traffic:
         json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
         print("pmc_traffic.json:", {k: round(v["bytes_per_launch"] / 1e6) for k, v in traffic.items()})
-sq = [os.path.join(SRC, d) for d in ("1x128_sq1", "1x128_sq2", "1x128_sq3") if one(f"{d}/**/*counter_collection.csv")]
+sq = [os.path.join(SRC, d) for d in ("1x128_sq1", "1x128_sq2", "1x128_sq3") if "cql" in SECTIONS and one(f"{d}/**/*counter_collection.csv")]
 if sq:
     run_tool("pmc_sq.py", sq, "r03_pmc_sq_counters_1x128.txt",
              f"# SQ counters per kernel (means per dispatch), CQL one engine x 128 runs, split precision (fp16 planes), commit {commit}: three separate rocprofv3 --kernel-trace --pmc passes\n"
              "# (units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_VALU_MFMA_COEXEC_CYCLES count cycles)\n")
 # few runs
 out = [f"# Kernel nodes per step in the few-runs regime (graph replay; rocprofv3 --kernel-trace, tools/trace_summary.py), commit {commit}\n"]
-for r in (1, 8):
+for r in ((1, 8) if "few" in SECTIONS else ()):
     t = one(f"few_{r}/**/*kernel_trace.csv")
     if not t:
         continue
