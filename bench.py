@@ -592,7 +592,7 @@ def main():
                             reps_s=rr, seconds_timed=float(np.sum(rr)), engines_per_gpu=E, runs_per_engine=R, roofline=r32)
                 for g in es:
                     g.close()
-            others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac")}
+            others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
         cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {

@@ -17,6 +17,9 @@ import numpy as np
 WORKLOADS = {
     "cql": dict(task="halfcheetah-medium-v2", obs=17, act=6, n=1_000_000, hidden=[256, 256],
                 over=dict(num_repeat_actions=10, target_entropy=-6.0), gflop=None),
+    # the reference CLI's own default depth (run_cql.py:31: hidden [256, 256, 256]); SURVEY 8(d): 15.00 GFLOP per gradient step
+    "cql_h3": dict(algo="cql", task="halfcheetah-medium-v2", obs=17, act=6, n=1_000_000, hidden=[256, 256, 256],
+                   over=dict(num_repeat_actions=10, target_entropy=-6.0), gflop=15.0),
     "iql": dict(task="hopper-medium-replay-v2", obs=11, act=3, n=400_000, hidden=[256, 256],
                 over=dict(expectile=0.7, iql_temperature=3.0), gflop=0.559),
     "td3bc": dict(task="halfcheetah-medium-v2", obs=17, act=6, n=1_000_000, hidden=[256, 256],
@@ -95,6 +98,7 @@ def make_engine(algo, n_runs, precision, device, seed, hidden=None, ws_one_round
                precision=precision, seed=1234 + 7919 * seed, ws_one_round=int(ws_one_round))
     cfg.update(w["over"])
     cfg.update(over)
+    algo = w.get("algo", algo)                       # WORKLOADS key -> engine algorithm
     eng = _engine.Engine(_engine.default_config(algo, **cfg))
     for r in range(n_runs):
         rng = np.random.RandomState(1000 + seed * 4096 + r)
@@ -110,7 +114,7 @@ def make_engine(algo, n_runs, precision, device, seed, hidden=None, ws_one_round
 
 def workload_string(algo, n_runs, engines=1, hidden=None):
     w = WORKLOADS[algo]
-    extra = {"cql": "10 repeat actions, auto-alpha", "iql": "expectile 0.7, temperature 3.0", "td3bc": "policy noise 0.2, actor every 2nd step",
+    extra = {"cql": "10 repeat actions, auto-alpha", "cql_h3": "10 repeat actions, auto-alpha (the reference CLI's default depth)", "iql": "expectile 0.7, temperature 3.0", "td3bc": "policy noise 0.2, actor every 2nd step",
              "edac": "10 critics, eta 5.0, auto-alpha"}[algo]
-    return (f"{algo.upper()} {w['task']} shape: obs{w['obs']}/act{w['act']}, batch {BATCH}, MLP {list(hidden or w['hidden'])}, {extra}, "
+    return (f"{w.get('algo', algo).upper()} {w['task']} shape: obs{w['obs']}/act{w['act']}, batch {BATCH}, MLP {list(hidden or w['hidden'])}, {extra}, "
             f"{w['n']} synthetic transitions, device sampling+noise, {engines} engine(s) x {n_runs} run(s)")

@@ -534,6 +534,31 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
       return 0;
     }
   }
+  // the same fused kernel fed with a MATERIALISED gradient (a three-layer net's middle layer): dz0 = 1[h0 > 0] (dz1 W1) never leaves the
+  // registers, dW0 / db0 come out as one slab per workgroup
+  if (w0_X && w0_slabs && !store_dx && maskH && !dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar && ws_precision_ok() &&
+      p.aux_bits && dy.m.pitch == out && ncols == in && (long)M * nz >= ws_wgrad_min_rows) {
+    WsDgradP w;
+    memset(&w, 0, sizeof(w));
+    w.Z = dy.m.p; w.z_s0 = dy.m.rs; w.z_s1 = dy.m.cs; w.z_pitch = dy.m.pitch;
+    w.xbits = maskH->bits; w.xb_s0 = maskH->brs; w.xb_s1 = maskH->bcs; w.xb_g = maskH->bg;
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer]; w.w_sn = 1; w.w_sk = in;
+    w.X = w0_X->p; w.x_s0 = w0_X->rs; w.x_s1 = w0_X->cs; w.x_pitch = w0_X->pitch; w.in0 = l.layer_in(0);
+    float* g = grads + nr.g_off;
+    w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
+    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    if (ws_dgrad_supported(w, out, in)) {
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
+      prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
+                 nz * (4.0 * in * out + 4.0 * M * (double)out + M * (double)in / 8 + 4.0 * M * (w0_X->pitch + 1) + 4.0 * per_z * in * (l.layer_in(0) + 1)));
+      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
+      *w0_slabs = per_z;
+      return 0;
+    }
+  }
   if (w0_X && w0_slabs && maskH && layer == 1 && col0 == 0 && !l.ens && !force_scalar) {
     // fuse the layer-0 weight / bias gradient into this launch's epilogue (one slab per row tile)
     const int slabs = w0_fused_slabs(p, nz, l.layer_in(0), w0_X->pitch, w0_X->p, w0_X->rs, w0_X->cs, max_slab);
@@ -685,6 +710,27 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
       *fuse_tail = true;
+      *slabs_out = per_z;
+      return 0;
+    }
+  }
+  // the same output-stationary kernel for a hidden layer BELOW the top one of a many-row batch: dZ is a materialised matrix (three products
+  // per block instead of the rank-1 form's two, no mask / w_tail); one slab per workgroup
+  if (slabs_out && !dy.rank1 && with_bias && slab0 == 0 && ws_precision_ok() && !force_scalar && !l.ens && !x_dscale && in_row0 == 0 &&
+      in_rows == in && X.pitch == in && dy.m.pitch == out && (long)M * nz >= ws_wgrad_min_rows) {
+    WsWgradP w;
+    memset(&w, 0, sizeof(w));
+    w.dZ = dy.m.p; w.dz_s0 = dy.m.rs; w.dz_s1 = dy.m.cs; w.dz_pitch = dy.m.pitch;
+    w.H0 = X.p; w.h0_s0 = X.rs; w.h0_s1 = X.cs; w.h0_pitch = X.pitch;
+    w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
+    w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    if (ws_wgrad_supported(w, out, in)) {
+      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);
+      prof_begin(tag, 2.0 * M * (double)in * (out + 1) * nz, nz * (4.0 * M * (double)(in + out) + 4.0 * per_z * out * (in + 1)));
+      hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
       *slabs_out = per_z;
       return 0;
     }

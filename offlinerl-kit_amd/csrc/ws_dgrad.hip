@@ -3,28 +3,34 @@
 
 namespace orl {
 
-template <bool W0, bool STORE>
+// PLAIN: the incoming gradient is a materialised matrix (WsDgradP::Z) -- A image = its hi and lo planes, B' = W1, no dq in the epilogue
+template <bool W0, bool STORE, bool PLAIN = false>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
+  static_assert(!PLAIN || (W0 && !STORE), "the plain variant exists for the fused layer-0 gradient only");
+  constexpr int APL = PLAIN ? 2 : 1;                                // planes of the A image
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  hx_t* Ah = (hx_t*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled
-  hx_t* XT = Ah + 2 * WS_ROWS * WS_PITCH;                        // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
+  hx_t* Ah = (hx_t*)ws_smem;                                   // [buf][row][256] 0/1 mask as bf16, swizzled   (PLAIN: [buf][hi, lo][row][256])
+  hx_t* XT = Ah + 2 * APL * WS_ROWS * WS_PITCH;                  // [buf][hi, lo][c = 32][WD_XP]: X^T of the row group
   float* EO = (float*)(XT + 2 * 2 * 32 * WD_XP);                   // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]: epilogue operands
   __shared__ u32x2_t mlut[16];                                     // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
-  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const unsigned int* __restrict__ ab = PLAIN ? nullptr : p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
   const unsigned int* __restrict__ xb = p.xbits + z0 * p.xb_s0 + z1 * p.xb_s1;
-  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ dqg = PLAIN ? nullptr : p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
-  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ wtg = PLAIN ? nullptr : p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const float* __restrict__ Zg = PLAIN ? p.Z + z0 * p.z_s0 + z1 * p.z_s1 : nullptr;
   const int ncol0 = 32 * wave;
-  // split precision: dq enters scaled by the run's dynamic gradient scale (W0 variant only: the stored dz0 of the STORE variant must be
-  // the true values), the resident products by ORL_WWSCALE; dz0 therefore carries gs * ORL_WWSCALE into the second MFMA stage
+  // split precision: dq (PLAIN: dz1) enters scaled by the run's dynamic gradient scale (W0 variant only: the stored dz0 of the STORE variant
+  // must be the true values), the resident products by ORL_WWSCALE (PLAIN: ORL_WSCALE); dz0 therefore carries gs * that scale into the
+  // second MFMA stage
   const float gsc = (W0 && p.gscale) ? p.gscale[z0] : 1.f;
+  constexpr float BSC = PLAIN ? ORL_WSCALE : ORL_WWSCALE;
   const float dq_sc = W0 ? gsc : 1.0f / ORL_WWSCALE;                // factor applied to dq when it is staged
-  const float out_inv = 1.0f / (gsc * ORL_WWSCALE);                  // W0: applied to the dW0 / db0 slab
+  const float out_inv = 1.0f / (gsc * BSC);                          // W0: applied to the dW0 / db0 slab
 
   // resident B' fragments: lane (li, lq) supplies B'[k = 32 ks + 8 lq + j][n = ncol0 + 16 cb + li] = w_tail[k] * W1[k][n]
   hx8 bh[2][8], bl[2][8];
@@ -33,12 +39,13 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
       const int n = ncol0 + 16 * cb + li, k0 = 32 * ks + 8 * lq;
-      const f32x4 t0 = *(const f32x4*)&wtg[k0], t1 = *(const f32x4*)&wtg[k0 + 4];
+      f32x4 t0 = (f32x4){1.f, 1.f, 1.f, 1.f}, t1 = t0;
+      if (!PLAIN) { t0 = *(const f32x4*)&wtg[k0]; t1 = *(const f32x4*)&wtg[k0 + 4]; }
       f32x4 a, b;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        a[j] = (t0[j] * ORL_WWSCALE) * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];       // static scale, divided out below
-        b[j] = (t1[j] * ORL_WWSCALE) * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
+        a[j] = (t0[j] * BSC) * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];       // static scale, divided out below
+        b[j] = (t1[j] * BSC) * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
       }
       ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
     }
@@ -64,6 +71,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   }
   float sdq;
   unsigned int sxw;
+  f32x4 sz[PLAIN ? 4 : 1];                                          // PLAIN: the thread's four pieces of the dz1 row group (row (tid >> 6) + 8 i, columns 4 (tid & 63) ..)
+  const unsigned int vo_z = PLAIN ? (unsigned int)((tid >> 6) * p.z_pitch + 4 * (tid & 63)) : 0u;
   // global addresses = scalar row-group base + per-thread offset computed once (no 64-bit vector multiplies in the loop)
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1)), vo_dq = (unsigned int)((tid & 31) * (int)p.dq_sm);
   const unsigned int vo_xb = (unsigned int)(((tid >> 3) & 31) * p.xb_g + (tid & 7));
@@ -72,10 +81,15 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
   for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; vo_x[i] = (unsigned int)(e < xe ? e : (xe > 0 ? xe - 1 : 0)); }   // clamped, not predicated
   auto load_group = [&](int g) __attribute__((always_inline)) {
     const long row0 = (long)g * WS_ROWS;
-    sm_word = (ab + row0 * p.ab_g)[vo_ab];
-    // the epilogue's dq and h0 mask words travel through LDS with the group (fetched a full iteration ahead by the staging threads:
-    // the epilogue then has no global loads of its own to wait for)
-    sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    if (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sz[i] = *(const f32x4*)&(Zg + (row0 + 8 * i) * p.z_pitch)[vo_z];
+    } else {
+      sm_word = (ab + row0 * p.ab_g)[vo_ab];
+      // the epilogue's dq and h0 mask words travel through LDS with the group (fetched a full iteration ahead by the staging threads:
+      // the epilogue then has no global loads of its own to wait for)
+      sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    }
     sxw = (xb + row0 * p.xb_g)[vo_xb];
     if (W0) {
 #pragma unroll
@@ -83,6 +97,19 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
+    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
+    if (PLAIN) {
+      hx_t* dh = Ah + (long)buf * 2 * WS_ROWS * WS_PITCH;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 6) + 8 * i, kq = tid & 63;              // columns 4 kq ..: half (kq & 1) of the 16-byte chunk kq >> 1
+        hx4 h, l;
+        orl_split4(sz[i] * gsc, h, l);
+        const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
+        *(hx4*)(dh + o) = h;
+        *(hx4*)(dh + WS_ROWS * WS_PITCH + o) = l;
+      }
+    } else {
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     u32x4 c0, c1;                                                    // 16 bf16 values: 1.0 = 0x3F80 where the bit is set
@@ -93,8 +120,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     hx_t* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
-    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
     eo[tid & 31] = sdq * dq_sc;                                      // (replicated writes of identical values)
+    }
     ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
     hx_t* xt = XT + (long)buf * 2 * 32 * WD_XP;
 #pragma unroll
@@ -131,12 +158,12 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
     const float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      dq4[s] = *(const f32x4*)&eo[16 * s + 4 * lq];
+      dq4[s] = PLAIN ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)&eo[16 * s + 4 * lq];
       const u32x4 w4 = *(const u32x4*)&((const unsigned int*)eo)[WS_ROWS + wave * WS_ROWS + 16 * s + 4 * lq];
 #pragma unroll
       for (int r = 0; r < 4; ++r) xw[s][r] = w4[r];
     }
-    const hx_t* ah = Ah + (long)buf * WS_ROWS * WS_PITCH;
+    const hx_t* ah = Ah + (long)buf * APL * WS_ROWS * WS_PITCH;
     f32x4 acc[WS_SUB][2];
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s)
@@ -147,9 +174,12 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
         const hx8 fa = *(const hx8*)&ah[(16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3)];
+        hx8 fl;
+        if (PLAIN) fl = *(const hx8*)&ah[WS_ROWS * WS_PITCH + (16 * s + li) * WS_PITCH + (((4 * ks + lq) ^ li) << 3)];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {               // D[m][n]: lane holds rows 4 lq + r of column li
           acc[s][cb] = ORL_MFMA_16x16x32(fa, bl[cb][ks], acc[s][cb]);
+          if (PLAIN) acc[s][cb] = ORL_MFMA_16x16x32(fl, bh[cb][ks], acc[s][cb]);
           acc[s][cb] = ORL_MFMA_16x16x32(fa, bh[cb][ks], acc[s][cb]);
         }
       }
@@ -173,7 +203,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
         // (element by element: gathering the four values first and splitting them with orl_split4 measured 15 % slower here)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4[s][r] : 0.f;
+          const float v = ((xw[s][r] >> (16 * cb + li)) & 1u) ? (PLAIN ? acc[s][cb][r] : acc[s][cb][r] * dq4[s][r]) : 0.f;
           if (STORE) Cg[(long)(g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + 16 * cb + li] = v;
           hx_t hh, ll;
           orl_split1(v, hh, ll);
@@ -221,22 +251,24 @@ static constexpr size_t ws_dgrad32_lds_bytes() {
   return sizeof(float) * ((size_t)2 * WS_ROWS * WS_K + (size_t)2 * 32 * WD32_XP + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS));
 }
 
-template <bool W0, bool STORE>
+template <bool W0, bool STORE, bool PLAIN = false>                   // PLAIN: A image = the materialised dz1 rows (WsDgradP::Z), B' = W1
 __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "one 32-column mask word per wave, 32-row groups");
+  static_assert(!PLAIN || (W0 && !STORE), "the plain variant exists for the fused layer-0 gradient only");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  float* Am = ws_smem;                                              // [buf][row][256] 0/1 mask as fp32, swizzled
+  float* Am = ws_smem;                                              // [buf][row][256] 0/1 mask as fp32, swizzled   (PLAIN: the dz1 values)
   float* XT = Am + 2 * WS_ROWS * WS_K;                              // [buf][c = 32][WD32_XP]: X^T of the row group
   float* EO = XT + 2 * 32 * WD32_XP;                                // [buf][dq[32] | h0 mask words [wave = 8][row = 32]]
   __shared__ f32x4 mlut32[16];                                      // 4 mask bits -> 4 floats (0.0 / 1.0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
-  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const unsigned int* __restrict__ ab = PLAIN ? nullptr : p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
   const unsigned int* __restrict__ xb = p.xbits + z0 * p.xb_s0 + z1 * p.xb_s1;
-  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const float* __restrict__ dqg = PLAIN ? nullptr : p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
-  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ wtg = PLAIN ? nullptr : p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const float* __restrict__ Zg = PLAIN ? p.Z + z0 * p.z_s0 + z1 * p.z_s1 : nullptr;
   const int ncol0 = 32 * wave;
 
   f32x4 bw[2][16];
@@ -245,9 +277,10 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int n = ncol0 + 16 * cb + li, k0 = 16 * t + 4 * lq;
-      const f32x4 t0 = *(const f32x4*)&wtg[k0];
+      f32x4 t0 = (f32x4){1.f, 1.f, 1.f, 1.f};
+      if (!PLAIN) t0 = *(const f32x4*)&wtg[k0];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bw[cb][t][j] = t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
+      for (int j = 0; j < 4; ++j) bw[cb][t][j] = PLAIN ? Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk] : t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
     }
   if (W0) for (int e = tid; e < 2 * 32 * WD32_XP; e += WS_NT) XT[e] = 0.f;      // rows c >= x_pitch are never written again
   if (tid < 16) mlut32[tid] = (f32x4){(float)(tid & 1), (float)((tid >> 1) & 1), (float)((tid >> 2) & 1), (float)(tid >> 3)};
@@ -267,6 +300,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
   }
   float sdq;
   unsigned int sxw;
+  f32x4 sz[PLAIN ? 4 : 1];                                          // PLAIN: row (tid >> 6) + 8 i, columns 4 (tid & 63) .. of the dz1 row group
+  const unsigned int vo_z = PLAIN ? (unsigned int)((tid >> 6) * p.z_pitch + 4 * (tid & 63)) : 0u;
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1)), vo_dq = (unsigned int)((tid & 31) * (int)p.dq_sm);
   const unsigned int vo_xb = (unsigned int)(((tid >> 3) & 31) * p.xb_g + (tid & 7));
   unsigned int vo_x[2];
@@ -274,8 +309,13 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
   for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; vo_x[i] = (unsigned int)(e < xe ? e : (xe > 0 ? xe - 1 : 0)); }
   auto load_group = [&](int g) __attribute__((always_inline)) {      // scalar row-group base + per-thread offset (see ws_dgrad_w0_kernel)
     const long row0 = (long)g * WS_ROWS;
-    sm_word = (ab + row0 * p.ab_g)[vo_ab];
-    sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    if (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sz[i] = *(const f32x4*)&(Zg + (row0 + 8 * i) * p.z_pitch)[vo_z];
+    } else {
+      sm_word = (ab + row0 * p.ab_g)[vo_ab];
+      sdq = (dqg + row0 * p.dq_sm)[vo_dq];
+    }
     sxw = (xb + row0 * p.xb_g)[vo_xb];
     if (W0) {
 #pragma unroll
@@ -283,14 +323,22 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
     }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
+    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
+    if (PLAIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = (tid >> 6) + 8 * i, kq = tid & 63;              // chunk kq = columns 4 kq ..
+        *(f32x4*)(Am + (long)buf * WS_ROWS * WS_K + r * WS_K + ((kq ^ (r & 15)) << 2)) = sz[i];
+      }
+    } else {
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     float* d = Am + (long)buf * WS_ROWS * WS_K + r * WS_K;
 #pragma unroll
     for (int j = 0; j < 4; ++j)                                      // chunk 4 hw + j = columns 16 hw + 4 j ..; 4 bits -> 4 floats: LDS table
       *(f32x4*)(d + (((4 * hw + j) ^ (r & 15)) << 2)) = mlut32[(bits >> (4 * j)) & 15u];
-    float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
     eo[tid & 31] = sdq;
+    }
     ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
     float* xt = XT + (long)buf * 32 * WD32_XP;
 #pragma unroll
@@ -340,7 +388,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
     const float* xt = XT + (long)buf * 32 * WD32_XP;
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) {
-      const f32x4 dq4s = *(const f32x4*)&eo[16 * s + 4 * lq];
+      const f32x4 dq4s = PLAIN ? (f32x4){1.f, 1.f, 1.f, 1.f} : *(const f32x4*)&eo[16 * s + 4 * lq];
       const u32x4 xws = *(const u32x4*)&((const unsigned int*)eo)[WS_ROWS + wave * WS_ROWS + 16 * s + 4 * lq];
       f32x4 xa[2];
       if (W0) {
@@ -352,7 +400,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
         f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = ((xws[r] >> (16 * cb + li)) & 1u) ? acc[s][cb][r] * dq4s[r] : 0.f;
+          v[r] = ((xws[r] >> (16 * cb + li)) & 1u) ? (PLAIN ? acc[s][cb][r] : acc[s][cb][r] * dq4s[r]) : 0.f;
           if (STORE) Cg[(long)(g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + 16 * cb + li] = v[r];
         }
 #pragma unroll
@@ -390,11 +438,19 @@ hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st) {
     static const hipError_t attr_err = [] {
       hipError_t e = hipFuncSetAttribute((const void*)ws_dgrad32_w0_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad32_lds_bytes());
       if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_dgrad32_w0_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad32_lds_bytes());
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_dgrad32_w0_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad32_lds_bytes());
       return e;
     }();
     if (attr_err != hipSuccess) return attr_err;
-    if (p.w0_out) hipLaunchKernelGGL((ws_dgrad32_w0_kernel<true, false>), grid, block, ws_dgrad32_lds_bytes(), st, p);
+    if (p.Z) hipLaunchKernelGGL((ws_dgrad32_w0_kernel<true, false, true>), grid, block, ws_dgrad32_lds_bytes(), st, p);
+    else if (p.w0_out) hipLaunchKernelGGL((ws_dgrad32_w0_kernel<true, false>), grid, block, ws_dgrad32_lds_bytes(), st, p);
     else hipLaunchKernelGGL((ws_dgrad32_w0_kernel<false, true>), grid, block, ws_dgrad32_lds_bytes(), st, p);
+    return hipGetLastError();
+  }
+  if (p.Z) {
+    static const hipError_t attr_err = hipFuncSetAttribute((const void*)ws_dgrad_w0_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_dgrad_lds_bytes(true));
+    if (attr_err != hipSuccess) return attr_err;
+    hipLaunchKernelGGL((ws_dgrad_w0_kernel<true, false, true>), grid, block, ws_dgrad_lds_bytes(true), st, p);
     return hipGetLastError();
   }
   if (p.w0_out) hipLaunchKernelGGL((ws_dgrad_w0_kernel<true, false>), grid, block, ws_dgrad_lds_bytes(), st, p);

@@ -140,17 +140,26 @@ struct WsDgradP {
   const float* X; long x_s0, x_s1; int x_pitch, in0;           // layer-0 input rows [M][x_pitch], in0 + 1 <= 32
   float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
+  // PLAIN variant (Z != nullptr; W0 only): the incoming gradient is a materialised matrix dz1 [M][256] (a hidden layer below the top
+  // one) instead of (mask bits, dq, w_tail):  dz0 = 1[h0 > 0] * (dz1 W1),  dW0 / db0 as above.  The A image gets a lo plane (three
+  // products per block), B' = W1 itself.
+  const float* Z; long z_s0, z_s1; int z_pitch;
   int M, nz1, groups;
   int f32;                                                     // exact fp32 arithmetic (ws_dgrad32_w0_kernel) instead of the split 16-bit planes
-  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq, one float per run (z0); null = 1
+  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq / dz1, one float per run (z0); null = 1
 };
 enum { WD_XP = WS_ROWS + 4 };                                       // bf16 pitch of an X^T row (72 B: scattered 2-byte stores and 8-byte reads spread over the banks)
-static constexpr size_t ws_dgrad_lds_bytes() {     // mask images + X^T images + per-group epilogue operands (dq, h0 mask words)
-  return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
+static constexpr size_t ws_dgrad_lds_bytes(bool plain = false) {     // mask images (plain: hi + lo planes of dz1) + X^T images + per-group epilogue operands (dq, h0 mask words)
+  return (size_t)(plain ? 4 : 2) * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 2 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
 }
 
 static inline bool ws_dgrad_supported(const WsDgradP& p, int K, int N) {
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS)) return false;
+  if (p.Z) {
+    if (!p.w0_out || p.C || !p.xbits || p.xb_g != 8) return false;
+    if (!aligned16(p.Z) || (p.z_pitch & 3) || (p.z_s0 & 3) || (p.z_s1 & 3)) return false;
+    return !(p.in0 + 1 > 32 || p.in0 >= p.x_pitch || p.x_pitch > 32 || WS_ROWS * p.x_pitch > 2 * WS_NT);
+  }
   if (!p.abits || !p.xbits || p.ab_g != 8 || p.xb_g != 8) return false;
   if (p.w0_out && (p.in0 + 1 > 32 || p.in0 >= p.x_pitch || p.x_pitch > 32 || WS_ROWS * p.x_pitch > 2 * WS_NT)) return false;
   if (!p.w0_out && !p.C) return false;
@@ -195,14 +204,25 @@ struct WsWgradP {
   //   dw_tail[n] = sum_m dq[m] h1[m][n] = sum_k W1[n][k] G[n][k] + b1[n] g[n]      (linear in G, so it holds per slab)
   const float* W1; long w1_s0, w1_s1;                          // [256][256] (out, in) row-major
   const float* b1; long b1_s0, b1_s1;
+  // PLAIN variant (dZ != nullptr): the gradient w.r.t. this layer's output is a materialised matrix (a hidden layer below the top one):
+  //   dW[k][n] = sum_m dZ[m][k] * H0[m][n],  db[k] = sum_m dZ[m][k]
+  // Same output-stationary structure; the A operand has a lo plane now (three products per block instead of two), no mask, no w_tail.
+  const float* dZ; long dz_s0, dz_s1; int dz_pitch;
   int M, nz1, groups;
   int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of the split 16-bit planes
-  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq, one float per run (z0); null = 1
+  const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq / dZ, one float per run (z0); null = 1
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
-static constexpr size_t ws_wgrad_lds_bytes() { return (size_t)2 * 3 * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2; }   // 2 buffers x {mask, G hi, G lo} + dq blocks
+static constexpr size_t ws_wgrad_lds_bytes(bool plain = false) {   // 2 buffers x {mask, G hi, G lo} (plain: {dZ hi, dZ lo, H hi, H lo}) + dq / ones blocks
+  return (size_t)2 * (plain ? 4 : 3) * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2;
+}
 
 static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
+  if (p.dZ) {
+    if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS)) return false;
+    if (!aligned16(p.dZ) || (p.dz_pitch & 3) || (p.dz_s0 & 3) || (p.dz_s1 & 3)) return false;
+    return aligned16(p.H0) && !(p.h0_pitch & 3) && !(p.h0_s0 & 3) && !(p.h0_s1 & 3);
+  }
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.abits || p.ab_g != 8) return false;
   if (!aligned16(p.H0) || (p.h0_pitch & 3) || (p.h0_s0 & 3) || (p.h0_s1 & 3)) return false;
   if (!p.H1 && p.W1 && (!p.b1 || !p.dwt || !p.dbt)) return false;

@@ -29,6 +29,23 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
   const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
   float* dW = p.dW + so + z1 * p.o_s1w;
   float* db = p.db + so + z1 * p.o_s1b;
+  if (MODE == 3) {                                   // plain dZ: the accumulators are the gradient (no rank-1 factor)
+#pragma unroll
+    for (int kb = 0; kb < 16; ++kb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = acc[kb][nb][r] * inv;
+    if (li == 0) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int k0 = 16 * (2 * wave + x) + 4 * lq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db[k0 + r] = accb[x][r] * inv;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int kb = 0; kb < 16; ++kb) {
     const f32x4 w4 = *(const f32x4*)&wtg[16 * kb + 4 * lq];           // lane holds rows k = 16 kb + 4 lq + r, column n = ncol0 + 16 nb + li
@@ -107,21 +124,24 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
   }
 }
 
-template <int MODE>      // 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators
+// MODE 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators,
+//      3: PLAIN -- a materialised dZ instead of (mask, dq, w_tail): A gets a lo plane (three products per block), B = H0 itself
+template <int MODE>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
-  constexpr bool TAILS = (MODE == 1);
+  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3);
+  constexpr int NPL = PLAIN ? 4 : 3;                                // LDS planes per buffer
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  hx_t* img = (hx_t*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]
+  hx_t* img = (hx_t*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]   (PLAIN: {dZ hi, dZ lo, H hi, H lo})
   __shared__ u32x2_t mlut[16];                                      // 4 mask bits -> 4 bf16 values
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
-  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
-  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const unsigned int* __restrict__ ab = PLAIN ? nullptr : p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const float* __restrict__ dqg = PLAIN ? nullptr : p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
   const float* __restrict__ H0g = p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1;
-  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ wtg = PLAIN ? nullptr : p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const int ncol0 = 32 * wave;
-  // split precision: G = (dq * gs) (.) h0 with the run's dynamic power-of-two gradient scale gs, divided out of the slab in ww_finish
+  // split precision: G = (dq * gs) (.) h0 (PLAIN: dZ * gs) with the run's dynamic power-of-two gradient scale gs, divided out of the slab in ww_finish
   const float gsc = p.gscale ? p.gscale[z0] : 1.f;
 
   f32x4 acc[16][2], accb[2];
@@ -133,27 +153,29 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 
   // ---- staging registers of one row group ----
   f32x4 s0[4];
-  f32x4 s1[TAILS ? 4 : 1];
+  f32x4 s1[(TAILS || PLAIN) ? 4 : 1];
   f32x4 tacc = (f32x4){0.f, 0.f, 0.f, 0.f}, bacc = (f32x4){0.f, 0.f, 0.f, 0.f};   // TAILS: dw_tail / db1 partials of columns 4 (tid & 63) ..
   float dqsum = 0.f;
-  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
+  // second streamed matrix: TAILS h1 (registers only), PLAIN dZ (the A operand)
+  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : (PLAIN ? p.dZ + z0 * p.dz_s0 + z1 * p.dz_s1 : nullptr);
+  const int h1_pitch = PLAIN ? p.dz_pitch : p.h1_pitch;
   float sdq[4];
   unsigned int sm_word;
-  hx_t* dqimg = img + 2 * 3 * WW_IMG;                              // [buf][hi, lo][32 rows][16]: column 0 = dq, others 0 (db1 operand)
+  hx_t* dqimg = img + 2 * NPL * WW_IMG;                            // [buf][hi, lo][32 rows][16]: column 0 = dq (PLAIN: 1), others 0 (db1 operand)
   // Global addresses = (uniform part: row group and piece, scalar ALU) + (per-thread part, computed once): the loop carries no vector
   // address arithmetic (64-bit multiplies cost a SIMD 4 - 7 cycles each, and vector instructions do not overlap with its MFMAs).
   const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
-  const unsigned int vo_h1 = TAILS ? (unsigned int)((tid >> 6) * p.h1_pitch + 4 * (tid & 63)) : 0u;
+  const unsigned int vo_h1 = (TAILS || PLAIN) ? (unsigned int)((tid >> 6) * h1_pitch + 4 * (tid & 63)) : 0u;
   const unsigned int vo_dq = (unsigned int)((tid >> 6) * (int)p.dq_sm);
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
     const long row0 = (long)g * WS_ROWS + 8 * i;                      // uniform: rows row0 + (tid >> 6)
     s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
-    if (TAILS) s1[i] = *(const f32x4*)&(H1g + row0 * p.h1_pitch)[vo_h1];
-    sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
+    if (TAILS || PLAIN) s1[i] = *(const f32x4*)&(H1g + row0 * h1_pitch)[vo_h1];
+    if (!PLAIN) sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
   auto load_mask = [&](int g) __attribute__((always_inline)) {
-    sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
+    if (!PLAIN) sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
   };
   auto load_group = [&](int g) __attribute__((always_inline)) {
     load_mask(g);
@@ -161,7 +183,8 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) load_piece(g, i);
   };
   auto store_mask = [&](int buf) __attribute__((always_inline)) {
-    hx_t* mi = img + (long)buf * 3 * WW_IMG;
+    if (PLAIN) return;
+    hx_t* mi = img + (long)buf * NPL * WW_IMG;
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
     u32x4 c0, c1;
@@ -174,13 +197,23 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     *(u32x4*)(mi + ww_off(r, 2 * hw + 1, 0)) = c1;
   };
   auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
-    hx_t* gh = img + (long)buf * 3 * WW_IMG + WW_IMG;
+    hx_t* gh = img + (long)buf * NPL * WW_IMG + (NPL - 2) * WW_IMG;
     hx_t* gl = gh + WW_IMG;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
     hx4 h, l;
+    const int o = ww_off(r, kq >> 1, kq & 1);
+    if (PLAIN) {
+      orl_split4(s0[i], h, l);
+      *(hx4*)(gh + o) = h;
+      *(hx4*)(gl + o) = l;
+      hx_t* zh = img + (long)buf * NPL * WW_IMG;
+      orl_split4(s1[i] * gsc, h, l);
+      *(hx4*)(zh + o) = h;
+      *(hx4*)(zh + WW_IMG + o) = l;
+      return;
+    }
     const float dqs = sdq[i] * gsc;
     orl_split4(s0[i] * dqs, h, l);
-    const int o = ww_off(r, kq >> 1, kq & 1);
     *(hx4*)(gh + o) = h;
     *(hx4*)(gl + o) = l;
     if (TAILS) {
@@ -201,6 +234,10 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
   if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
+  if (PLAIN) {                                                     // db = dZ^T 1: column 0 of the hi block = 1.0 for every row, both buffers
+    __syncthreads();
+    if (tid < 2 * WS_ROWS) (dqimg + (long)(tid >> 5) * 2 * WS_ROWS * 16)[(tid & 31) * 16] = (hx_t)1.0f;
+  }
   if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
   __syncthreads();
 
@@ -216,8 +253,9 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   auto iteration = [&](int g, int it, bool steady) __attribute__((always_inline)) {
     const int buf = it & 1;
     const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
-    const hx_t* mi = img + (long)buf * 3 * WW_IMG;
-    const hx_t* gh = mi + WW_IMG;
+    const hx_t* mi = img + (long)buf * NPL * WW_IMG;
+    const hx_t* ml = mi + WW_IMG;                                    // PLAIN: lo plane of dZ
+    const hx_t* gh = mi + (NPL - 2) * WW_IMG;
     const hx_t* gl = gh + WW_IMG;
     const hx_t* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
     {
@@ -245,12 +283,20 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
       for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
         const int kb0 = 2 * kp, kb1 = kb0 + 1;
-        const hx8 a0 = cat(ww_tr(mi, 0, 16 * kb0, lane), ww_tr(mi, 16, 16 * kb0, lane));   // A[i = k][kk = m] = mask[m][k]
+        const hx8 a0 = cat(ww_tr(mi, 0, 16 * kb0, lane), ww_tr(mi, 16, 16 * kb0, lane));   // A[i = k][kk = m] = mask[m][k]   (PLAIN: dZ hi)
         const hx8 a1 = cat(ww_tr(mi, 0, 16 * kb1, lane), ww_tr(mi, 16, 16 * kb1, lane));
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bl[nb], acc[kb0][nb]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bl[nb], acc[kb1][nb]);
+        if (PLAIN) {                                                 // lo(dZ) * hi(H)
+          const hx8 l0 = cat(ww_tr(ml, 0, 16 * kb0, lane), ww_tr(ml, 16, 16 * kb0, lane));
+          const hx8 l1 = cat(ww_tr(ml, 0, 16 * kb1, lane), ww_tr(ml, 16, 16 * kb1, lane));
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(l0, bh[nb], acc[kb0][nb]);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(l1, bh[nb], acc[kb1][nb]);
+        }
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bh[nb], acc[kb0][nb]);
 #pragma unroll
@@ -258,8 +304,15 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
         if (!TAILS && kp == 7) {                                     // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
           const hx8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
           const hx8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
-          accb[0] = ORL_MFMA_16x16x32(c0, bdl, accb[0]);
-          accb[1] = ORL_MFMA_16x16x32(c1, bdl, accb[1]);
+          if (PLAIN) {                                               // the ones block has no lo plane; dZ has
+            const hx8 e0 = cat(ww_tr(ml, 0, 32 * wave, lane), ww_tr(ml, 16, 32 * wave, lane));
+            const hx8 e1 = cat(ww_tr(ml, 0, 32 * wave + 16, lane), ww_tr(ml, 16, 32 * wave + 16, lane));
+            accb[0] = ORL_MFMA_16x16x32(e0, bdh, accb[0]);
+            accb[1] = ORL_MFMA_16x16x32(e1, bdh, accb[1]);
+          } else {
+            accb[0] = ORL_MFMA_16x16x32(c0, bdl, accb[0]);
+            accb[1] = ORL_MFMA_16x16x32(c1, bdl, accb[1]);
+          }
           accb[0] = ORL_MFMA_16x16x32(c0, bdh, accb[0]);
           accb[1] = ORL_MFMA_16x16x32(c1, bdh, accb[1]);
         }
@@ -295,18 +348,19 @@ static constexpr size_t ws_wgrad32_lds_bytes() { return sizeof(float) * ((size_t
 template <int MODE>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
-  constexpr bool TAILS = (MODE == 1);
+  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3);          // PLAIN: a materialised dZ as the A image, B = H0 itself (ws_gemm.h)
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-  float* img = ws_smem;                                             // [buf][{mask, G}][32][WW32_P]
+  float* img = ws_smem;                                             // [buf][{mask, G}][32][WW32_P]   (PLAIN: {dZ, H0})
   float* dqs = img + 2 * 2 * WW32_IMG;                              // [buf][32]
   __shared__ f32x4 mlut[16];                                        // 4 mask bits -> 4 floats (0.0 / 1.0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
-  const unsigned int* __restrict__ ab = p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
-  const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
+  const unsigned int* __restrict__ ab = PLAIN ? nullptr : p.abits + z0 * p.ab_s0 + z1 * p.ab_s1;
+  const float* __restrict__ dqg = PLAIN ? nullptr : p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
   const float* __restrict__ H0g = p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1;
-  const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
-  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : nullptr;
+  const float* __restrict__ wtg = PLAIN ? nullptr : p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ H1g = TAILS ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 : (PLAIN ? p.dZ + z0 * p.dz_s0 + z1 * p.dz_s1 : nullptr);
+  const int h1_pitch = PLAIN ? p.dz_pitch : p.h1_pitch;
   const int ncol0 = 32 * wave;
 
   f32x4 acc[16][2], accb[2];
@@ -316,24 +370,24 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     for (int nb = 0; nb < 2; ++nb) acc[kb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   accb[0] = accb[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 s0[4];
-  f32x4 s1[TAILS ? 4 : 1];
+  f32x4 s1[(TAILS || PLAIN) ? 4 : 1];
   f32x4 tacc = (f32x4){0.f, 0.f, 0.f, 0.f}, bacc = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dqsum = 0.f;
   float sdq[4];
   unsigned int sm_word;
   // (uniform part of every global address on the scalar ALU, per-thread part computed once: see ws_wgrad_kernel)
   const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
-  const unsigned int vo_h1 = TAILS ? (unsigned int)((tid >> 6) * p.h1_pitch + 4 * (tid & 63)) : 0u;
+  const unsigned int vo_h1 = (TAILS || PLAIN) ? (unsigned int)((tid >> 6) * h1_pitch + 4 * (tid & 63)) : 0u;
   const unsigned int vo_dq = (unsigned int)((tid >> 6) * (int)p.dq_sm);
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
     const long row0 = (long)g * WS_ROWS + 8 * i;
     s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
-    if (TAILS) s1[i] = *(const f32x4*)&(H1g + row0 * p.h1_pitch)[vo_h1];
-    sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
+    if (TAILS || PLAIN) s1[i] = *(const f32x4*)&(H1g + row0 * h1_pitch)[vo_h1];
+    if (!PLAIN) sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
   auto load_mask = [&](int g) __attribute__((always_inline)) {
-    sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
+    if (!PLAIN) sm_word = (ab + (long)g * WS_ROWS * p.ab_g)[vo_ab];
   };
   auto load_group = [&](int g) __attribute__((always_inline)) {
     load_mask(g);
@@ -341,6 +395,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     for (int i = 0; i < 4; ++i) load_piece(g, i);
   };
   auto store_mask = [&](int buf) __attribute__((always_inline)) {      // thread (row r, half-word hw): 16 mask bits -> 16 floats
+    if (PLAIN) return;
     float* mi = img + (long)buf * 2 * WW32_IMG;
     const int r = tid >> 4, hw = tid & 15;
     const unsigned int bits = (sm_word >> (16 * (hw & 1))) & 0xFFFFu;
@@ -350,6 +405,11 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
     float* gi = img + (long)buf * 2 * WW32_IMG + WW32_IMG;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    if (PLAIN) {
+      *(f32x4*)(gi + r * WW32_P + 4 * kq) = s0[i];
+      *(f32x4*)(gi - WW32_IMG + r * WW32_P + 4 * kq) = s1[i];          // the A image: dZ
+      return;
+    }
     *(f32x4*)(gi + r * WW32_P + 4 * kq) = s0[i] * sdq[i];
     if (TAILS) {
 #pragma unroll
@@ -387,7 +447,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     for (int st = 0; st < 8; ++st) {
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) bg[nb][st] = gi[4 * st * WW32_P + ro + ncol0 + 16 * nb];
-      if (!TAILS) { const float d = dqb[4 * st + lq]; bd[st] = li == 0 ? d : 0.f; }
+      if (!TAILS) { const float d = PLAIN ? 1.0f : dqb[4 * st + lq]; bd[st] = li == 0 ? d : 0.f; }
     }
 #pragma unroll
     for (int kp = 0; kp < 8; ++kp) {
@@ -438,10 +498,17 @@ hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes(true));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (p.dZ) {                                      // plain (materialised) gradient: a hidden layer below the top one
+    if (p.f32) hipLaunchKernelGGL(ws_wgrad32_kernel<3>, grid, block, ws_wgrad32_lds_bytes(), st, p);
+    else hipLaunchKernelGGL(ws_wgrad_kernel<3>, grid, block, ws_wgrad_lds_bytes(true), st, p);
+    return hipGetLastError();
+  }
   if (p.f32) {
     if (p.H1) hipLaunchKernelGGL(ws_wgrad32_kernel<1>, grid, block, ws_wgrad32_lds_bytes(), st, p);
     else if (p.W1) hipLaunchKernelGGL(ws_wgrad32_kernel<2>, grid, block, ws_wgrad32_lds_bytes(), st, p);

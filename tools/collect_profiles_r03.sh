@@ -28,7 +28,7 @@ if [ "$what" = all ] || [ "$what" = few ]; then
   done
 fi
 if [ "$what" = all ] || [ "$what" = algos ]; then
-  for a in iql td3bc edac; do
+  for a in iql td3bc edac cql_h3; do
     echo "== $a: tags + kernel stats + pmc"
     python3 tools/algo_run.py $a 128 1 30 --tags $O/tags_$a.txt > $O/run_$a.log 2>&1
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/${a}_stats -o r -- python3 tools/algo_run.py $a 128 1 30 > $O/${a}_stats.log 2>&1

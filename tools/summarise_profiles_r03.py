@@ -70,7 +70,7 @@ B = "python3 bench.py --steps 20 --warmup 5 --no-sides --no-cpu-baseline --profi
 if "cql" in SECTIONS:
   copy_stats("default_stats", "r03_cql_default_2x96_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B}  (2 engines x 96 runs, split precision; with two engines wall durations of one engine's launches include waiting behind the other's)")
   copy_stats("1x128_stats", "r03_cql_1x128_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B} --engines-per-gpu 1 --runs-per-gpu 128")
-for a in (("iql", "td3bc", "edac") if "algos" in SECTIONS else ()):
+for a in (("iql", "td3bc", "edac", "cql_h3") if "algos" in SECTIONS else ()):
     copy_stats(f"{a}_stats", f"r03_{a}_128runs_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- python3 tools/algo_run.py {a} 128 1 30")
     t = os.path.join(SRC, f"tags_{a}.txt")
     if os.path.exists(t):
