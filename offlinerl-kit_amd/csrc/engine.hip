@@ -537,7 +537,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   // the same fused kernel fed with a MATERIALISED gradient (a three-layer net's middle layer): dz0 = 1[h0 > 0] (dz1 W1) never leaves the
   // registers, dW0 / db0 come out as one slab per workgroup
   if (w0_X && w0_slabs && !store_dx && maskH && !dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar && ws_precision_ok() &&
-      p.aux_bits && dy.m.pitch == out && ncols == in && (long)M * nz >= ws_wgrad_min_rows) {
+      p.aux_bits && dy.m.pitch == out && ncols == in && (long)M * nz >= ws_dgrad_plain_min_rows) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
     w.Z = dy.m.p; w.z_s0 = dy.m.rs; w.z_s1 = dy.m.cs; w.z_pitch = dy.m.pitch;
@@ -1009,6 +1009,7 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
+  { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
   { const char* f = getenv("ORL_WS32"); use_ws32 = !(f && atoi(f) == 0); }
