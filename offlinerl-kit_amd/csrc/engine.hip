@@ -363,7 +363,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   if (cfg == CFG_SQ) cfg = CFG_SQ8;          // forward products: the 8-wave flavour of the 128 x 128 tile measured faster
   // weight-stationary row-streaming kernel (csrc/ws_gemm.h) for the many-row 256 x 256 hidden layers in split-bf16 precision
   if (epi == E_BIAS_RELU && ws_precision_ok() && !no_ws && !force_scalar && in_row0 == 0 && in_rows == in &&
-      Y.bits && Y.pitch == out && (long)M * nz >= 4096) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
+      Y.bits && Y.pitch == out && (long)M * nz >= ws_fwd_min_rows) {   // measured faster than the 16x64 tiles from 16 x 256 rows up
     WsFwdP w;
     memset(&w, 0, sizeof(w));
     w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch;
@@ -488,7 +488,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   // weight-stationary fused kernel (csrc/ws_gemm.h): top-layer dgrad from mask bits + layer-0 weight gradient, nothing stored
   if (w0_X && w0_slabs && !store_dx && maskH && dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar &&
       ws_precision_ok() && p.aux_bits && dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch &&
-      ncols == in && (long)M * nz >= 4096) {
+      ncols == in && (long)M * nz >= ws_bwd_min_rows) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
     w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
@@ -514,7 +514,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   }
   // same kernel, storing variant (no layer-0 gradient): e.g. the critic backward of the actor loss, where dz0 feeds dL/da
   if (!(w0_X && w0_slabs) && maskH && dy.rank1 && col0 == 0 && !force_scalar && ws_precision_ok() && p.aux_bits &&
-      dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= 4096) {
+      dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && ncols == in && dX.pitch >= in && (long)M * nz >= ws_bwd_min_rows) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
     w.abits = dy.m.bits; w.ab_s0 = dy.m.brs; w.ab_s1 = dy.m.bcs; w.ab_g = dy.m.bg;
@@ -574,7 +574,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   // plain (materialised) dz through a 256 x 256 layer with the ReLU mask of the receiving activation: the weight-stationary kernel
   // in gradient mode (B = the weights viewed transposed, epilogue = mask from bits)
   if (!dy.rank1 && !p.w0_out && maskH && p.aux_bits && col0 == 0 && ncols == in && ws_precision_ok() && !force_scalar &&
-      dy.m.pitch == out && dX.pitch == in && (long)M * nz >= 4096) {
+      dy.m.pitch == out && dX.pitch == in && (long)M * nz >= ws_bwd_min_rows) {
     WsFwdP w;
     memset(&w, 0, sizeof(w));
     w.X = dy.m.p; w.x_s0 = dy.m.rs; w.x_s1 = dy.m.cs; w.x_pitch = dy.m.pitch;
@@ -1010,6 +1010,8 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipStreamSynchronize(stream));
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
+  { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
+  { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
   { const char* f = getenv("ORL_WS32"); use_ws32 = !(f && atoi(f) == 0); }
