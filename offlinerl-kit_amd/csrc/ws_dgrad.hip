@@ -34,21 +34,31 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 
   // resident B' fragments: lane (li, lq) supplies B'[k = 32 ks + 8 lq + j][n = ncol0 + 16 cb + li] = w_tail[k] * W1[k][n]
   hx8 bh[2][8], bl[2][8];
+  {
+    // all 128 loads of the lane are issued before the first conversion (one exposed memory latency instead of sixteen)
+    f32x4 raw[2][8][2];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int n = ncol0 + 16 * cb + li, k0 = 32 * ks + 8 * lq;
-      f32x4 t0 = (f32x4){1.f, 1.f, 1.f, 1.f}, t1 = t0;
-      if (!PLAIN) { t0 = *(const f32x4*)&wtg[k0]; t1 = *(const f32x4*)&wtg[k0 + 4]; }
-      f32x4 a, b;
+      for (int ks = 0; ks < 8; ++ks) {
+        const int n = ncol0 + 16 * cb + li, k0 = 32 * ks + 8 * lq;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a[j] = (t0[j] * BSC) * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];       // static scale, divided out below
-        b[j] = (t1[j] * BSC) * Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
+        for (int j = 0; j < 4; ++j) {
+          raw[cb][ks][0][j] = Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
+          raw[cb][ks][1][j] = Wg[(long)n * p.w_sn + (long)(k0 + 4 + j) * p.w_sk];
+        }
       }
-      ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
-    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int k0 = 32 * ks + 8 * lq;
+        f32x4 t0 = (f32x4){1.f, 1.f, 1.f, 1.f}, t1 = t0;
+        if (!PLAIN) { t0 = *(const f32x4*)&wtg[k0]; t1 = *(const f32x4*)&wtg[k0 + 4]; }
+        // static scale BSC, divided out below
+        ws_split8((t0 * BSC) * raw[cb][ks][0], (t1 * BSC) * raw[cb][ks][1], bh[cb][ks], bl[cb][ks]);
+      }
+  }
   // zero both X^T images once (rows c >= x_pitch are never written again)
   if (W0) for (int e = tid; e < 2 * 2 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;
   if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
@@ -273,15 +283,19 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
 
   f32x4 bw[2][16];
 #pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
+  for (int cb = 0; cb < 2; ++cb)                                    // (all loads first, then the w_tail products: see ws_dgrad_w0_kernel)
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       const int n = ncol0 + 16 * cb + li, k0 = 16 * t + 4 * lq;
-      f32x4 t0 = (f32x4){1.f, 1.f, 1.f, 1.f};
-      if (!PLAIN) t0 = *(const f32x4*)&wtg[k0];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bw[cb][t][j] = PLAIN ? Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk] : t0[j] * Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
+      for (int j = 0; j < 4; ++j) bw[cb][t][j] = Wg[(long)n * p.w_sn + (long)(k0 + j) * p.w_sk];
     }
+  if (!PLAIN) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) bw[cb][t] *= *(const f32x4*)&wtg[16 * t + 4 * lq];
+  }
   if (W0) for (int e = tid; e < 2 * 32 * WD32_XP; e += WS_NT) XT[e] = 0.f;      // rows c >= x_pitch are never written again
   if (tid < 16) mlut32[tid] = (f32x4){(float)(tid & 1), (float)((tid >> 1) & 1), (float)((tid >> 2) & 1), (float)(tid >> 3)};
   __syncthreads();

@@ -33,33 +33,49 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   // F32: lane (li, lq) supplies W[n][k = 16 t + 4 lq .. + 3], t = 0..15 (element e of the float4 = MFMA k step e of block t)
   hx8 bh[WS_CB][F32 ? 1 : 8], bl[WS_CB][F32 ? 1 : 8];
   f32x4 bw[WS_CB][F32 ? 16 : 1];
+  // The layout test (w_sk == 1) sits OUTSIDE the fragment loops and all loads of a layout are issued before the first conversion: with the
+  // test inside, every fragment was its own load -> wait -> split round trip (16 - 32 serialized L2 latencies = the ~20 us floor of a launch)
   if constexpr (F32) {
+    if (p.w_sk == 1) {
 #pragma unroll
-    for (int cb = 0; cb < WS_CB; ++cb)
+      for (int cb = 0; cb < WS_CB; ++cb)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(16 * t + 4 * lq) * p.w_sk;
-        if (p.w_sk == 1) bw[cb][t] = *(const f32x4*)src;
-        else {
+        for (int t = 0; t < 16; ++t) bw[cb][t] = *(const f32x4*)(Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (16 * t + 4 * lq));
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(16 * t + 4 * lq) * p.w_sk;
 #pragma unroll
           for (int j = 0; j < 4; ++j) bw[cb][t][j] = src[(long)j * p.w_sk];
         }
-      }
-  } else {
-#pragma unroll
-  for (int cb = 0; cb < WS_CB; ++cb)
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
-      // the resident weights carry the static scale ORL_WSCALE (divided out in the epilogue): hi stays in fp16's normal range
-      if (p.w_sk == 1) ws_split8(*(const f32x4*)src * ORL_WSCALE, *(const f32x4*)(src + 4) * ORL_WSCALE, bh[cb][ks], bl[cb][ks]);
-      else {                                           // (in, out)-major weights: eight strided loads, once per workgroup
-        f32x4 a, b;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = src[(long)j * p.w_sk] * ORL_WSCALE; b[j] = src[(long)(4 + j) * p.w_sk] * ORL_WSCALE; }
-        ws_split8(a, b, bh[cb][ks], bl[cb][ks]);
-      }
     }
+  } else {
+    // the resident weights carry the static scale ORL_WSCALE (divided out in the epilogue): hi stays in fp16's normal range
+    f32x4 raw[WS_CB][8][2];
+    if (p.w_sk == 1) {
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (32 * ks + 8 * lq);
+          raw[cb][ks][0] = *(const f32x4*)src; raw[cb][ks][1] = *(const f32x4*)(src + 4);
+        }
+    } else {                                           // (in, out)-major weights: eight strided loads per fragment, once per workgroup
+#pragma unroll
+      for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const float* src = Wg + (long)(ncol0 + 16 * cb + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { raw[cb][ks][0][j] = src[(long)j * p.w_sk]; raw[cb][ks][1][j] = src[(long)(4 + j) * p.w_sk]; }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < WS_CB; ++cb)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) ws_split8(raw[cb][ks][0] * ORL_WSCALE, raw[cb][ks][1] * ORL_WSCALE, bh[cb][ks], bl[cb][ks]);
   }
   // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
   hx8 b0h[WS_CB], b0l[WS_CB];
