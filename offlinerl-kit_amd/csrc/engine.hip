@@ -798,6 +798,38 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   const NetLayout& l = *nr.lay;
   const int Ln = l.L;
   std::string t = tag;
+  // few batched rows (one to a few runs per engine): the whole pass as ONE launch (small_fwd.h) instead of layer 0 + layer 1 + tail
+  if (small_fwd_on && Ln == 2 && !l.ens && !no_ws && !force_scalar && l.H[0] == SF_N && l.H[1] == SF_N && hs[0].pitch == SF_N && hs[1].pitch == SF_N &&
+      (long)M * R * nr.nz1 < ws_fwd_min_rows) {
+    SmallFwdP w;
+    memset(&w, 0, sizeof(w));
+    w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch; w.in0 = l.layer_in(0);
+    w.W0 = nr.base + l.w_off[0]; w.w0_s0 = nr.rs; w.w0_s1 = l.w_ms[0];
+    w.b0 = nr.base + l.b_off[0]; w.b0_s0 = nr.rs; w.b0_s1 = l.b_ms[0];
+    w.W1 = nr.base + l.w_off[1]; w.w1_s0 = nr.rs; w.w1_s1 = l.w_ms[1];
+    w.b1 = nr.base + l.b_off[1]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[1];
+    w.Wt = nr.base + l.w_off[2]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[2];
+    w.bt = nr.base + l.b_off[2]; w.bt_s0 = nr.rs; w.bt_s1 = l.b_ms[2];
+    if (!fwd_only) {
+      w.H0 = hs[0].p; w.h0_s0 = hs[0].rs; w.h0_s1 = hs[0].cs;
+      w.H1 = hs[1].p; w.h1_s0 = hs[1].rs; w.h1_s1 = hs[1].cs;
+    }
+    w.OUT = out.p; w.o_s0 = out.rs; w.o_s1 = out.cs; w.o_pitch = out.pitch; w.out_dim = l.out_dim;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
+    if (small_fwd_supported(w)) {
+      const int nz = R * nr.nz1;
+      prof_begin(tag, 2.0 * M * (double)nz * (SF_N * (double)(w.in0 + 1) + (double)SF_N * SF_N + (double)SF_N * l.out_dim),
+                 4.0 * nz * (M * (double)(X.pitch + (fwd_only ? 0 : 2 * SF_N) + l.out_dim) + (double)SF_N * (w.in0 + SF_N + l.out_dim + 2)));
+      hipError_t err = launch_small_fwd(w, nz, stream);
+      prof_end();
+      if (err != hipSuccess) return fail(std::string("small_fwd launch ") + tag + ": " + hipGetErrorString(err));
+      for (int i = 0; i < 2; ++i) {
+        if (hs[i].bits) bits_live.erase(hs[i].bits);      // no packed masks from this path: the backward reads 1[h > 0] from the values
+        if (fwd_only) vals_dead.insert(hs[i].p); else vals_dead.erase(hs[i].p);
+      }
+      return 0;
+    }
+  }
   bool tail_done = false;
   for (int i = 0; i < Ln; ++i) {
     if (i == 0 && Ln >= 2) continue;         // layer 0 is issued together with layer 1 (fused into it when the ws kernel applies)
@@ -1011,6 +1043,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
+  { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
   { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }

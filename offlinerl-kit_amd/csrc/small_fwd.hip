@@ -1,0 +1,272 @@
+// small_fwd.hip — fused forward of a [in0 -> 256 -> 256 -> out] net for few batched rows (interface and design notes: small_fwd.h).
+#include "small_fwd.h"
+
+namespace orl {
+
+// LDS layout (bytes).  Split planes: 16-bit elements; F32: floats.
+//   A    : the 32 rows' current activation, all 256 k   (split: hi + lo planes [32][SF_AP], F32: [32][SF_AF])
+//   W    : two buffers of one 32-wide k chunk of the layer's weights for all 256 output units (split: hi + lo [256][SF_WP], F32: [256][SF_WF])
+//   X    : the 32 input rows, K padded to 32, ones column at in0 (split: hi + lo [32][SF_WP], F32: [32][SF_WF])
+//   WT   : tail weights [16][256] fp32, b1 [256], bt [16]
+//   the cross-wave reduction of the tail reuses the W buffers after the last chunk
+enum { SF_AP = 264, SF_WP = 40, SF_AF = 260, SF_WF = 36 };
+template <bool F32> static constexpr size_t sf_a_bytes() { return F32 ? (size_t)SF_ROWS * SF_AF * 4 : (size_t)2 * SF_ROWS * SF_AP * 2; }
+template <bool F32> static constexpr size_t sf_w_bytes() { return F32 ? (size_t)2 * SF_N * SF_WF * 4 : (size_t)2 * 2 * SF_N * SF_WP * 2; }
+template <bool F32> static constexpr size_t sf_x_bytes() { return F32 ? (size_t)SF_ROWS * SF_WF * 4 : (size_t)2 * SF_ROWS * SF_WP * 2; }
+template <bool F32> static constexpr size_t sf_lds_bytes() {
+  return sf_a_bytes<F32>() + sf_w_bytes<F32>() + sf_x_bytes<F32>() + (size_t)(SF_MAXOUT * SF_N + SF_N + SF_MAXOUT) * 4;
+}
+static_assert(sf_w_bytes<false>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4 && sf_w_bytes<true>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4, "tail reduction fits the chunk buffers");
+
+template <bool F32>
+__global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
+  unsigned char* sA = sf_smem;
+  unsigned char* sW = sA + sf_a_bytes<F32>();
+  unsigned char* sX = sW + sf_w_bytes<F32>();
+  float* sWT = (float*)(sX + sf_x_bytes<F32>());
+  float* sB1 = sWT + SF_MAXOUT * SF_N;
+  float* sBT = sB1 + SF_N;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
+  const int g = blockIdx.x, z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
+  const int ncol0 = 32 * wave;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1 + (long)g * SF_ROWS * p.x_pitch;
+  const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
+  const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
+  const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
+  const float* __restrict__ b1g = p.b1 + z0 * p.b1_s0 + z1 * p.b1_s1;
+  const float* __restrict__ Wtg = p.Wt + z0 * p.wt_s0 + z1 * p.wt_s1;
+  const float* __restrict__ btg = p.bt + z0 * p.bt_s0 + z1 * p.bt_s1;
+
+  // ---- one 32-wide k chunk of weights: thread t moves the float4 (unit n = (t + 512 i) >> 3, k = 4 ((t + 512 i) & 7) ..), i = 0..3 ----
+  // ALL nine chunks are requested up front (144 VGPRs): a workgroup has one 32-row group to do, so there is exactly one memory latency to
+  // hide and nothing to hide it behind -- with one chunk in flight per iteration the launch took 15 - 19 us, nine exposed round trips
+  f32x4 wr[9][4];
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {      // c = 0: [W0 | b0 | 0] (layer 0, K = 32); c = 1..8: columns 32 (c - 1) .. of W1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + SF_NT * i, n = e >> 3, q = e & 7;
+      if (c == 0) {
+        // clamped addresses and a multiply by 0 / 1, not guarded loads or selects: the compiler sinks a load whose value is only selected
+        // under a condition back into a branch of its own, each with its own wait (16 serialized round trips per thread, ~10 us per launch).
+        // (0 * w keeps the padding exact for finite weights; a diverged run's Inf / NaN would spread into the zero columns -- of a net that
+        // is already lost)
+        const float bn = b0g[n];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 4 * q + j;
+          const float w = W0g[(long)n * p.in0 + (k < p.in0 ? k : p.in0 - 1)];
+          wr[c][i][j] = (k < p.in0 ? 1.f : 0.f) * w + (k == p.in0 ? 1.f : 0.f) * bn;
+        }
+      } else wr[c][i] = *(const f32x4*)&W1g[(long)n * SF_N + 32 * (c - 1) + 4 * q];
+    }
+  };
+  auto store_chunk = [&](int c) __attribute__((always_inline)) {     // chunk c -> LDS buffer c & 1
+    const int buf = c & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + SF_NT * i, n = e >> 3, q = e & 7;
+      if constexpr (F32) *(f32x4*)((float*)sW + ((long)buf * SF_N + n) * SF_WF + 4 * q) = wr[c][i];
+      else {
+        hx_t* wh = (hx_t*)sW + (long)buf * 2 * SF_N * SF_WP;
+        hx4 h, l;
+        orl_split4(wr[c][i] * ORL_WSCALE, h, l);                     // static weight scale, divided out in the epilogues
+        *(hx4*)(wh + n * SF_WP + 4 * q) = h;
+        *(hx4*)(wh + SF_N * SF_WP + n * SF_WP + 4 * q) = l;
+      }
+    }
+  };
+
+  // ---- prologue: EVERY global load of the launch is issued before the first LDS store (one exposed memory latency): input rows (ones
+  // column at in0, zero beyond), tail constants, all nine weight chunks ----
+  float xs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + SF_NT * i, r = e >> 5, k = e & 31;
+    const float x = Xg[(long)r * p.x_pitch + (k < p.in0 ? k : p.in0 - 1)];
+    xs[i] = (k < p.in0 ? 1.f : 0.f) * x + (k == p.in0 ? 1.0f : 0.f);
+  }
+  const int nwt = p.out_dim * SF_N;                                // tail weights: up to two float4 per thread
+  const bool wt_vec = (((uintptr_t)Wtg) & 15) == 0;
+  f32x4 wts[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = 4 * (tid + SF_NT * i);
+    const int ec = e < nwt ? e : nwt - 4;                        // clamped (rows beyond out_dim are never read back)
+    if (wt_vec) wts[i] = *(const f32x4*)&Wtg[ec];
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wts[i][j] = Wtg[ec + j];
+    }
+  }
+  const float b1v = b1g[tid & (SF_N - 1)], btv = btg[tid < p.out_dim ? tid : 0];
+#pragma unroll
+  for (int c = 0; c <= 8; ++c) load_chunk(c);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + SF_NT * i, r = e >> 5, k = e & 31;
+    if constexpr (F32) ((float*)sX)[r * SF_WF + k] = xs[i];
+    else {
+      hx_t hh, ll;
+      orl_split1(xs[i], hh, ll);
+      ((hx_t*)sX)[r * SF_WP + k] = hh;
+      ((hx_t*)sX)[SF_ROWS * SF_WP + r * SF_WP + k] = ll;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = 4 * (tid + SF_NT * i);
+    if (e < nwt) *(f32x4*)&sWT[e] = wts[i];
+  }
+  if (tid < SF_N) sB1[tid] = b1v;
+  if (tid < p.out_dim) sBT[tid] = btv;
+  store_chunk(0);
+  __syncthreads();
+
+  f32x4 acc[2][2];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) acc[s][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+  constexpr float inv_sc = F32 ? 1.0f : 1.0f / ORL_WSCALE;
+  float* __restrict__ H0g = p.H0 ? p.H0 + z0 * p.h0_s0 + z1 * p.h0_s1 + (long)g * SF_ROWS * SF_N : nullptr;
+  float* __restrict__ H1g = p.H1 ? p.H1 + z0 * p.h1_s0 + z1 * p.h1_s1 + (long)g * SF_ROWS * SF_N : nullptr;
+
+  // products of chunk c: operands swapped (weights first), lane (li, lq) then holds C[m = 16 s + li][n = ncol0 + 16 cb + 4 lq + r]
+  auto compute = [&](int c) __attribute__((always_inline)) {
+    const int buf = c & 1;
+    if constexpr (F32) {
+      const float* wf = (const float*)sW + (long)buf * SF_N * SF_WF;
+      const float* af = c == 0 ? (const float*)sX : (const float*)sA + 32 * (c - 1);
+      const int apitch = c == 0 ? SF_WF : SF_AF;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 fa[2], fw[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fa[s] = *(const f32x4*)&af[(16 * s + li) * apitch + 16 * t + 4 * lq];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) fw[cb] = *(const f32x4*)&wf[(ncol0 + 16 * cb + li) * SF_WF + 16 * t + 4 * lq];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[cb][e], fa[s][e], acc[s][cb], 0, 0, 0);
+      }
+    } else {
+      const hx_t* wh = (const hx_t*)sW + (long)buf * 2 * SF_N * SF_WP;
+      const hx_t* wl = wh + SF_N * SF_WP;
+      const hx_t* ah = c == 0 ? (const hx_t*)sX : (const hx_t*)sA + 32 * (c - 1);
+      const int apitch = c == 0 ? SF_WP : SF_AP;
+      const hx_t* al = ah + (c == 0 ? SF_ROWS * SF_WP : SF_ROWS * SF_AP);
+      hx8 fah[2], fal[2], fwh[2], fwl[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        fah[s] = *(const hx8*)&ah[(16 * s + li) * apitch + 8 * lq];
+        fal[s] = *(const hx8*)&al[(16 * s + li) * apitch + 8 * lq];
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        fwh[cb] = *(const hx8*)&wh[(ncol0 + 16 * cb + li) * SF_WP + 8 * lq];
+        fwl[cb] = *(const hx8*)&wl[(ncol0 + 16 * cb + li) * SF_WP + 8 * lq];
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwl[cb], fah[s], acc[s][cb]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwh[cb], fal[s], acc[s][cb]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwh[cb], fah[s], acc[s][cb]);
+    }
+  };
+
+#pragma unroll
+  for (int c = 0; c <= 8; ++c) {
+    compute(c);
+    if (c + 1 <= 8) store_chunk(c + 1);             // that buffer was last read by compute(c - 1): every wave has passed the barrier since
+    if (c == 0) {
+      // layer-0 epilogue (the bias came in through the ones column): ReLU, optional store, the A image of layer 1
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          f32x4 v = acc[s][cb] * inv_sc;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+          const int m = 16 * s + li, n = ncol0 + 16 * cb + 4 * lq;
+          if (H0g) *(f32x4*)&H0g[(long)m * SF_N + n] = v;
+          if constexpr (F32) *(f32x4*)((float*)sA + m * SF_AF + n) = v;
+          else {
+            hx4 h, l;
+            orl_split4(v, h, l);
+            *(hx4*)((hx_t*)sA + m * SF_AP + n) = h;
+            *(hx4*)((hx_t*)sA + SF_ROWS * SF_AP + m * SF_AP + n) = l;
+          }
+        }
+      zero_acc();
+    }
+    __syncthreads();
+  }
+
+  // ---- layer-1 epilogue: bias, ReLU, optional store; tail = dot products of the wave's 32 columns, reduced across the eight waves ----
+  float* red = (float*)sW;                           // [wave][lane group][row][SF_MAXOUT]; the chunk buffers are dead (barrier above)
+  f32x4 v[2][2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int m = 16 * s + li, n = ncol0 + 16 * cb + 4 * lq;
+      f32x4 x = acc[s][cb] * inv_sc + *(const f32x4*)&sB1[n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[j] = x[j] > 0.f ? x[j] : 0.f;
+      if (H1g) *(f32x4*)&H1g[(long)m * SF_N + n] = x;
+      v[s][cb] = x;
+    }
+  // every lane leaves the partial sums of its eight columns in LDS (no cross-lane shuffles: a chain of dependent ds_bpermute per output
+  // cost the actor's 12-output tail ~3 us); 32 partials per (row, output) = 8 waves x 4 lane groups, summed in a fixed order below
+  for (int o = 0; o < p.out_dim; ++o) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float pd = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const f32x4 w = *(const f32x4*)&sWT[o * SF_N + ncol0 + 16 * cb + 4 * lq];
+        pd += (v[s][cb][0] * w[0] + v[s][cb][1] * w[1]) + (v[s][cb][2] * w[2] + v[s][cb][3] * w[3]);
+      }
+      red[(((wave * 4 + lq) * SF_ROWS) + 16 * s + li) * SF_MAXOUT + o] = pd;
+    }
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, o = tid & 15;
+    if (o < p.out_dim) {
+      float a = sBT[o];
+#pragma unroll
+      for (int w = 0; w < 32; ++w) a += red[(w * SF_ROWS + r) * SF_MAXOUT + o];      // fixed order
+      (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch + o] = a;
+    }
+  }
+}
+
+hipError_t launch_small_fwd(const SmallFwdP& p, int nz, hipStream_t st) {
+  static const hipError_t attr_err = [] {
+    hipError_t e = hipFuncSetAttribute((const void*)small_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<false>());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)small_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<true>());
+    return e;
+  }();
+  if (attr_err != hipSuccess) return attr_err;
+  const dim3 grid(p.M / SF_ROWS, 1, nz), block(SF_NT);
+  if (p.f32) hipLaunchKernelGGL(small_fwd_kernel<true>, grid, block, sf_lds_bytes<true>(), st, p);
+  else hipLaunchKernelGGL(small_fwd_kernel<false>, grid, block, sf_lds_bytes<false>(), st, p);
+  return hipGetLastError();
+}
+
+}  // namespace orl
