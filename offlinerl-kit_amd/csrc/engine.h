@@ -151,7 +151,8 @@ struct Engine {
   bool force_scalar = false;   // debug: disable the vector loaders
   int loss_nblk = 1;
   bool elide_top = true;       // many-row single-output nets: keep the top hidden activation out of HBM (ORL_WS_KEEP_H1=1 stores it)
-  bool small_fwd_on = true;      // below ws_fwd_min_rows batched rows a [in -> 256 -> 256 -> out] forward is ONE launch (small_fwd.h; ORL_SMALL_FWD=0: three tiled launches)
+  bool small_fwd_on = true;      // up to small_fwd_max_rows batched rows a [in -> 256 -> 256 -> out] forward is ONE launch (small_fwd.h; ORL_SMALL_FWD=0: tiled / weight-stationary launches)
+  long small_fwd_max_rows = 8192;   // measured: 8 / 16 runs per engine +4 % against the weight-stationary launch at 4096 .. 8192 rows, 32 runs (16384 rows) -1 % (ORL_SMALL_FWD_MAX)
   long ws_fwd_min_rows = 4096, ws_bwd_min_rows = 4096;   // batched rows from which the weight-stationary forward / dgrad kernels replace the tiled launches (ORL_WS_FWD_MIN / ORL_WS_BWD_MIN)
   long ws_dgrad_plain_min_rows = 40000;   // batched rows from which a middle layer's dgrad (+ dW0) runs on the plain weight-stationary kernel (ORL_WS_DGRAD_PLAIN_MIN overrides)
   long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)

@@ -800,7 +800,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   std::string t = tag;
   // few batched rows (one to a few runs per engine): the whole pass as ONE launch (small_fwd.h) instead of layer 0 + layer 1 + tail
   if (small_fwd_on && Ln == 2 && !l.ens && !no_ws && !force_scalar && l.H[0] == SF_N && l.H[1] == SF_N && hs[0].pitch == SF_N && hs[1].pitch == SF_N &&
-      (long)M * R * nr.nz1 < ws_fwd_min_rows) {
+      (long)M * R * nr.nz1 <= small_fwd_max_rows) {
     SmallFwdP w;
     memset(&w, 0, sizeof(w));
     w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch; w.in0 = l.layer_in(0);
@@ -1044,6 +1044,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
+  { const char* f = getenv("ORL_SMALL_FWD_MAX"); if (f && atol(f) > 0) small_fwd_max_rows = atol(f); }
   { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
   { const char* f = getenv("ORL_WS"); use_ws = !(f && atoi(f) == 0); }
