@@ -89,7 +89,8 @@ if "cql" in SECTIONS and one("1x96_FETCH_SIZE/**/*counter_collection.csv") and o
     txt = run_tool("pmc_summary.py", [os.path.join(SRC, "1x96_FETCH_SIZE"), os.path.join(SRC, "1x96_WRITE_SIZE")], "r03_pmc_summary_1x96_one_round.md",
                    f"## HBM traffic per launch, CQL, one engine x 96 runs, ORL_WS_ONE_ROUND=1 (the decomposition of the two-engine default), split precision (commit {commit})\nseparate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `{B} --engines-per-gpu 1 --runs-per-gpu 96`; gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x 2, counters in KiB)\n\n")
     traffic = {}
-    tags = {"ws_fwd_kernel<true, true, false, false, false>": "critic.fwd1", "ws_wgrad_kernel<2>": "critic.bwd.wgrad1", "ws_dgrad_w0_kernel<true, false>": "critic.bwd.dgrad1"}
+    tags = {"ws_fwd_kernel<true, true, false, false, false, true>": "critic.fwd1", "ws_wgrad_kernel<2>": "critic.bwd.wgrad1",
+            "ws_dgrad_w0_kernel<true, false, false>": "critic.bwd.dgrad1"}      # (template argument lists as of the plain / discard flavours)
     for line in txt.splitlines():
         m = re.match(r"\| `([^`]+)` \((\d+)( long| short)?\) \| (\d+) \| ([\d.]+) \| (\d+) \| (\d+) \|", line)
         if m and m.group(1) in tags and (m.group(3) or " long").strip() == "long":
