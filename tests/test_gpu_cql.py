@@ -242,6 +242,64 @@ def test_cql_fp32_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
         eng4.close(); eng1.close()
 
 
+@pytest.mark.parametrize("precision", [1, 0])
+def test_small_forward_kernel_matches_tiled_launches(monkeypatch, precision):
+    """Few runs per engine: every 256-row forward pass (actor, critic(s, pi(s)), actor on [s; s'], target critics) is ONE launch of
+    small_fwd_kernel (csrc/small_fwd.h: layer 0 + layer 1 + tail, weights streamed through LDS); an engine created with ORL_SMALL_FWD=0
+    issues the three tiled launches for the same math.  Same inputs -> losses and updated parameters agree to rounding (the fused kernel
+    computes the tail in fp32 vector arithmetic, the tiled path on the matrix cores)."""
+    case = "cql_halfcheetah"
+    R = 2
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.setenv("ORL_SMALL_FWD", "0")      # read at engine creation
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.delenv("ORL_SMALL_FWD")
+    loss_bar, mean_bar, frac_bar = ((2e-5, 3e-6, 2e-3) if precision == 1 else (2e-6, 3e-7, 3e-4))
+    try:
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            ma = enga.step(lead(b, R), lead(noise_list(n), R))
+            mb = engb.step(lead(b, R), lead(noise_list(n), R))
+            for r in range(R):
+                assert rel_err(ma[r], mb[r], floor=1e-2) < loss_bar, (k, r, ma[r], mb[r])
+        for nm in ("critic1", "critic2", "actor"):
+            a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < mean_bar, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < frac_bar, (nm, pn)
+    finally:
+        enga.close(); engb.close()
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_three_layer_plain_weight_stationary_kernels_match_tiled_kernels(monkeypatch, precision):
+    """[256,256,256] critics (the reference CLI's default depth), 8 runs: the middle layer's weight gradient and its dgrad (+ layer-0
+    weight gradient) run on the plain variants of the weight-stationary kernels (ws_wgrad_kernel<3> / ws_dgrad_w0_kernel<W0, false, PLAIN>
+    and their fp32 twins), fed with the materialised dz1.  An engine created with the row thresholds out of reach keeps both on the
+    tiled GEMMs.  Same inputs -> losses and updated critic parameters agree to rounding."""
+    case = "cql_halfcheetah_h3"
+    R = 8
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.setenv("ORL_WS_WGRAD_MIN", "1000000000")
+    monkeypatch.setenv("ORL_WS_DGRAD_PLAIN_MIN", "1000000000")
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.delenv("ORL_WS_WGRAD_MIN"); monkeypatch.delenv("ORL_WS_DGRAD_PLAIN_MIN")
+    loss_bar, mean_bar, frac_bar = ((2e-5, 3e-6, 2e-3) if precision == 1 else (2e-6, 3e-7, 3e-4))
+    try:
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            ma = enga.step(lead(b, R), lead(noise_list(n), R))
+            mb = engb.step(lead(b, R), lead(noise_list(n), R))
+            assert rel_err(ma[R - 1], mb[R - 1], floor=1e-2) < loss_bar, (k, ma[R - 1], mb[R - 1])
+        for nm in ("critic1", "critic2"):
+            a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < mean_bar, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < frac_bar, (nm, pn)
+    finally:
+        enga.close(); engb.close()
+
+
 @pytest.mark.parametrize("case", list(synth.CQL_EXTRA_CASES) + ["cql_halfcheetah_h3"])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_cql_many_runs_kernel_selection_corners(case, precision):
