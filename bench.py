@@ -453,7 +453,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=None,
                     help="independent engines per GPU (each --runs-per-gpu runs, own HIP stream and host thread): the launch-latency-bound "
                          "256-row phases of one engine overlap the many-row launches of the other (default 2)")
-    ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split-bf16 MFMA (parity-gated)")
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split MFMA (fp16 hi + lo planes; bf16 planes in the variant build) (parity-gated)")
     ap.add_argument("--min-reps", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=2.0)
     ap.add_argument("--no-sides", action="store_true", help="skip fp32 / by_runs / other_configs side records")

@@ -102,7 +102,7 @@ def _full_size_case(algo):
 @pytest.mark.parametrize("R", [16, 128])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
 def test_many_runs_split_bf16_follows_the_oracle(algo, R):
-    """16 / 128 runs per engine in split-bf16 precision: the 256-row phases of every algorithm then go through the run-batched
+    """16 / 128 runs per engine in split precision: the 256-row phases of every algorithm then go through the run-batched
     weight-stationary kernels where they apply (csrc/ws_gemm.h; the EDAC ensemble keeps the tiled kernels).  At 128 runs (the
     bench default) the twin critics reach the row count from which the top hidden activation is no longer stored and the
     tail-layer gradients are derived inside the output-stationary wgrad.  Identical inputs for all runs; every run must follow

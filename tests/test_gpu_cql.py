@@ -122,7 +122,7 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
             ora = np.array([res[x] for x in keys])
             for r in range(R):
                 assert rel_err(m[r], ora, floor=1e-2) < 1e-4, (k, r, m[r], ora)
-        for r in ((0, R - 1) if precision == 0 else ()):        # split-bf16 is gated on losses / Q-values only
+        for r in ((0, R - 1) if precision == 0 else ()):        # split precision is gated on losses / Q-values only
             for nm in ("critic1", "critic2", "actor"):
                 got = eng.get_net(r, NETS[nm])
                 for pn, v in got.items():
@@ -137,7 +137,7 @@ def test_cql_many_runs_full_size_matches_oracle(precision):
 
 @pytest.mark.parametrize("R", [96, 128])
 def test_cql_bench_sized_engine_follows_the_oracle(R):
-    """96 (bench.py's default engine) / 128 full-size runs per engine in split-bf16 precision: 192 / 256 batched critics -> one workgroup
+    """96 (bench.py's default engine) / 128 full-size runs per engine in split precision: 192 / 256 batched critics -> one workgroup
     per critic in the weight-stationary kernels, top hidden activation not stored, tail gradients derived in the wgrad.  Identical
     inputs for all runs; first, middle and last run must follow the oracle over three steps (the later steps see the updated
     parameters, i.e. the gradients of the earlier ones)."""
@@ -161,7 +161,7 @@ def test_cql_bench_sized_engine_follows_the_oracle(R):
 def test_cql_derived_tail_gradients_match_streamed_ones(monkeypatch, precision):
     """The engine normally keeps the critics' top hidden activation h1 out of HBM (mask bits only) and derives
     dw_tail = sum_k W1[n][k] G[n][k] + b1[n] g[n] from the wgrad accumulators; ORL_WS_KEEP_H1=1 stores h1 and streams it for
-    dw_tail = sum_m dq[m] h1[m][n].  Same inputs -> same losses and same updated tail parameters to rounding (split-bf16
+    dw_tail = sum_m dq[m] h1[m][n].  Same inputs -> same losses and same updated tail parameters to rounding (split-precision
     kernels and their exact-fp32 flavours ws_fwd_kernel<..., F32> / ws_wgrad32_kernel<1 | 2>)."""
     case = "cql_halfcheetah"
     R = 4
@@ -357,5 +357,5 @@ def test_cql_split_bf16_precision_meets_the_gate(case):
             for tap, gkey in (("q1", "step0/c1_q"), ("q2", "step0/c2_q"), ("q1a", "step0/c1_qa"), ("target_q", "step0/target_q")):
                 if gkey in g.files:
                     assert scale_err(eng.debug_read(0, tap), g[gkey]) < 1e-4, (tap, scale_err(eng.debug_read(0, tap), g[gkey]))
-    print(case, "worst loss rel err (split-bf16):", worst)
+    print(case, "worst loss rel err (split precision):", worst)
     eng.close()

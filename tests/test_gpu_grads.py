@@ -164,7 +164,7 @@ def test_cql_critic_backward_is_componentwise_backward_stable(R, precision):
 
 def check_params(eng, runs, nets, st, steps, tag, init=None, rel_bar=5e-2):
     """post-step parameters.  Adam's update is lr * m_hat / sqrt(v_hat): whatever |g| is, an element moves by ~lr per step, so an
-    element whose gradient is small against the gradient ERROR (relative L2 up to 4e-3 in split-bf16, see the module docstring)
+    element whose gradient is small against the gradient ERROR (relative L2 up to 4e-3 in the bf16-plane variant build, see the module docstring)
     lands a visible fraction of lr away -- the per-element bars of the fp32 tests (5 % of lr for 99.8 % of a tensor) do not transfer.
     What must hold: the mean deviation stays well below the step size (4e-6 * steps against lr = 1e-4 .. 3e-4; measured up to 2.8e-6 per step on the
     three-layer critics, where one flipped top-layer mask reaches two weight matrices below it),
@@ -190,7 +190,7 @@ def check_params(eng, runs, nets, st, steps, tag, init=None, rel_bar=5e-2):
 def test_cql_bench_configuration_gradients_and_parameters(R, precision):
     """(precision 0: the exact-fp32 flavours of the same kernels -- ws_fwd_kernel<..., F32>, ws_dgrad32_w0_kernel, ws_wgrad32_kernel<2>
     and, for the 256-row phases of >= 16 runs, the fp32 plain-dgrad / storing variants -- against the fp32 bars.)
-    CQL, halfcheetah shapes, split-bf16, R = 96 (bench.py's engine: 192 batched critics, 192 of 256 CUs) and 128 (256 critics):
+    CQL, halfcheetah shapes, split precision, R = 96 (bench.py's engine: 192 batched critics, 192 of 256 CUs) and 128 (256 critics):
     every gradient tensor of actor / critic1 / critic2 of the first, middle and last run against the oracle for two consecutive
     steps (the second step starts from Adam-updated parameters and targets), then the parameters after three steps.  Gradient bars:
     module docstring, check (2); from the second step on both sides start from parameters that already differ by Adam's
@@ -219,7 +219,7 @@ def test_cql_bench_configuration_gradients_and_parameters(R, precision):
 @pytest.mark.parametrize("precision", [1, 0])
 def test_cql_three_layer_gradients(precision):
     """reference CLI default [256,256,256] (run_cql.py:31): the middle layers go through the plain weight-stationary dgrad and the
-    tiled wgrads; 32 runs, split-bf16 and exact fp32"""
+    tiled wgrads; 32 runs, split precision and exact fp32"""
     from oracle import cql as ocql
     from offlinerlkit import _engine
     R = 32
@@ -251,7 +251,7 @@ GRAD_NETS = {
 @pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
 def test_other_algorithms_gradients_and_parameters_at_128_runs(algo, precision):
-    """IQL / TD3+BC / EDAC at 128 runs per engine in split-bf16 and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
+    """IQL / TD3+BC / EDAC at 128 runs per engine in split precision and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
     step 0, losses for three steps, parameters after three.  TD3+BC's actor only steps on even counts (td3bc.py:107): its gradient is
     compared on those steps."""
     R = 128

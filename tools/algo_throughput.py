@@ -1,4 +1,4 @@
-"""Gradient-steps/s of the four algorithms with device sampling (learn_n), one engine x R runs, split-bf16.
+"""Gradient-steps/s of the four algorithms with device sampling (learn_n), one engine x R runs, split precision.
 Uses the parity tests' full-size cases for shapes and initial weights; the replay buffer is synthetic.
 usage: python tools/algo_throughput.py [R] [STEPS]"""
 import os, sys, time
