@@ -1164,6 +1164,54 @@ __global__ void k_mcq_loss(McqLossP p) {
 //   L_g = mean_b sum_{i!=j} <g^_i, g^_j> / (K-1) ; gamma = d(eta L_g)/dg.   One thread per batch row.
 // grid (ceil(B/64), R), block 64; K*A <= 640 values per row kept in registers/LDS-free loops.
 // ================================================================================================
+// EDAC's adjoint sweep, first step (edac.py:136-149 restated analytically): t_0[b][j] = 1[h0[b][j] > 0] * sum_a gamma[b][a] * W0[od + a][j].
+// A product over the A (6) action inputs: as a GEMM it is all epilogue (217 us tiled); here every thread writes four consecutive j of one
+// row -- the launch is its 336 MB of output at the HBM rate.  fp32 FMAs in both precisions (exact-fp32 class arithmetic).
+struct EdacT0P {
+  const float* gamma; long g_rs, g_cs; int gpitch;      // [R][K][B][A]
+  const float* W; long w_rs, w_cs; int wpitch;          // action rows of the ensemble's first layer: W[a * wpitch + j], (in, out)-major
+  const float* h0; long h_rs, h_cs; int hpitch;         // activation values (mask source when no bits)
+  const unsigned int* bits; long b_rs, b_cs; int bg;    // packed mask words of h0, or null
+  float* out; long o_rs, o_cs; int opitch;
+  int B, A, N, K;
+};
+// one wave = all N columns (four per lane) of EDAC_T0_RB consecutive rows: the A weight rows stay in registers across the rows (loading them
+// per output element made the launch L1-bound: 13 loads per 16 bytes written, 1.6 TB/s)
+enum { EDAC_T0_RB = 8, EDAC_T0_AMAX = 8 };
+__global__ void k_edac_t0(EdacT0P p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int z1 = blockIdx.y, z0 = blockIdx.z;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const float* w = p.W + z0 * p.w_rs + z1 * p.w_cs;
+  const float* gbase = p.gamma + z0 * p.g_rs + z1 * p.g_cs;
+  float* out = p.out + z0 * p.o_rs + z1 * p.o_cs;
+  for (int j = 4 * lane; j < p.N; j += 256) {
+    f4 wr[EDAC_T0_AMAX];
+#pragma unroll
+    for (int a = 0; a < EDAC_T0_AMAX; ++a) wr[a] = a < p.A ? *(const f4*)&w[(long)a * p.wpitch + j] : (f4){0.f, 0.f, 0.f, 0.f};
+    const int b0 = EDAC_T0_RB * (blockIdx.x * (blockDim.x >> 6) + wave);
+#pragma unroll
+    for (int i = 0; i < EDAC_T0_RB; ++i) {
+      const int b = b0 + i;
+      if (b >= p.B) break;
+      const float* g = gbase + (long)b * p.gpitch;             // wave-uniform: scalar loads
+      f4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < EDAC_T0_AMAX; ++a) if (a < p.A) acc += g[a] * wr[a];
+      if (p.bits) {
+        const unsigned int m = (p.bits + z0 * p.b_rs + z1 * p.b_cs)[(long)b * p.bg + (j >> 5)] >> (j & 31);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = ((m >> r) & 1u) ? acc[r] : 0.f;
+      } else {
+        const f4 h = *(const f4*)&(p.h0 + z0 * p.h_rs + z1 * p.h_cs)[(long)b * p.hpitch + j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = h[r] > 0.f ? acc[r] : 0.f;
+      }
+      *(f4*)&out[(long)b * p.opitch + j] = acc;
+    }
+  }
+}
+
 struct EdacGP {
   const float* g; long g_rs, g_cs; int gpitch;   // [R][K][B][A]
   float* gamma;                                   // same layout
