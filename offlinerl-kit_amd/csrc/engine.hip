@@ -499,7 +499,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.X = w0_X->p; w.x_s0 = w0_X->rs; w.x_s1 = w0_X->cs; w.x_pitch = w0_X->pitch; w.in0 = l.layer_in(0);
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
-    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
+    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0); w.o_sc = 1;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
@@ -536,17 +536,20 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   }
   // the same fused kernel fed with a MATERIALISED gradient (a three-layer net's middle layer): dz0 = 1[h0 > 0] (dz1 W1) never leaves the
   // registers, dW0 / db0 come out as one slab per workgroup
-  if (w0_X && w0_slabs && !store_dx && maskH && !dy.rank1 && layer == 1 && col0 == 0 && !l.ens && !force_scalar && ws_precision_ok() &&
+  if (w0_X && w0_slabs && !store_dx && maskH && !dy.rank1 && layer == 1 && col0 == 0 && !force_scalar && ws_precision_ok() &&
       p.aux_bits && dy.m.pitch == out && ncols == in && (long)M * nz >= ws_dgrad_plain_min_rows) {
     WsDgradP w;
     memset(&w, 0, sizeof(w));
     w.Z = dy.m.p; w.z_s0 = dy.m.rs; w.z_s1 = dy.m.cs; w.z_pitch = dy.m.pitch;
     w.xbits = maskH->bits; w.xb_s0 = maskH->brs; w.xb_s1 = maskH->bcs; w.xb_g = maskH->bg;
-    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer]; w.w_sn = 1; w.w_sk = in;
+    w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
     w.X = w0_X->p; w.x_s0 = w0_X->rs; w.x_s1 = w0_X->cs; w.x_pitch = w0_X->pitch; w.in0 = l.layer_in(0);
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
-    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0);
+    w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train;
+    // nn.Linear keeps (out, in)-major weights, EnsembleLinear (in, out)-major ones: the same holds for the gradient slabs
+    if (l.ens) { w.w_sn = out; w.w_sk = 1; w.o_sr = 1; w.o_sc = l.layer_out(0); }
+    else { w.w_sn = 1; w.w_sk = in; w.o_sr = l.layer_in(0); w.o_sc = 1; }
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * cbk + 4 * lq + r, n = ncol0 + 16 * cb + li;
-        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r] * out_inv;
+        if (c < p.in0) wo[(long)n * p.o_sr + (long)c * p.o_sc] = d2[cbk][cb][r] * out_inv;
         else if (c == p.in0) bo[n] = d2[cbk][cb][r] * out_inv;
       }
 }
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad32_w0_kernel(const WsDgradP p) 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = 16 * cbk + 4 * lq + r, n = ncol0 + 16 * cb + li;
-        if (c < p.in0) wo[(long)n * p.o_sr + c] = d2[cbk][cb][r];
+        if (c < p.in0) wo[(long)n * p.o_sr + (long)c * p.o_sc] = d2[cbk][cb][r];
         else if (c == p.in0) bo[n] = d2[cbk][cb][r];
       }
 }

@@ -138,7 +138,7 @@ struct WsDgradP {
   const float* W; long w_s0, w_s1, w_sn, w_sk;                 // W1: element (k = output unit, n = input unit) at W[n * w_sn + k * w_sk]
                                                                //   nn.Linear (out, in): w_sn = 1, w_sk = 256; EnsembleLinear (in, out): 256, 1
   const float* X; long x_s0, x_s1; int x_pitch, in0;           // layer-0 input rows [M][x_pitch], in0 + 1 <= 32
-  float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr;   // slab outputs (dW0 [256][in0], db0 [256]); W0 variant
+  float* w0_out; float* b0_out; long o_s0, o_s1, ob_s1, o_ks; int o_sr, o_sc;   // slab outputs (dW0 element (unit n, input c) at n * o_sr + c * o_sc: nn.Linear (in0, 1), EnsembleLinear (1, 256); db0 [256]); W0 variant
   float* C; long c_s0, c_s1; int c_pitch;                      // dz0 [M][256]; STORE variant
   // PLAIN variant (Z != nullptr; W0 only): the incoming gradient is a materialised matrix dz1 [M][256] (a hidden layer below the top
   // one) instead of (mask bits, dq, w_tail):  dz0 = 1[h0 > 0] * (dz1 W1),  dW0 / db0 as above.  The A image gets a lo plane (three
