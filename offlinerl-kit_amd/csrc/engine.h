@@ -156,6 +156,9 @@ struct Engine {
   long ws_fwd_min_rows = 4096, ws_bwd_min_rows = 4096;   // batched rows from which the weight-stationary forward / dgrad kernels replace the tiled launches (ORL_WS_FWD_MIN / ORL_WS_BWD_MIN)
   long ws_dgrad_plain_min_rows = 40000;   // batched rows from which a middle layer's dgrad (+ dW0) runs on the plain weight-stationary kernel (ORL_WS_DGRAD_PLAIN_MIN overrides)
   long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)
+  int ws_wgrad_min_m = 1024;        // ... and rows PER NET: a 256-row net is 8 row groups behind a 256 KB slab write -- the tiled wgrad is faster there
+                                    // (IQL / TD3+BC at 128 runs: +1.2 %; ORL_WS_WGRAD_MIN_M overrides)
+  bool ws_wgrad_rows_ok(int M, int nz) const { return (long)M * nz >= ws_wgrad_min_rows && M >= ws_wgrad_min_m; }
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
   bool use_ws32 = true;        // ... and their exact-fp32 variants at precision 0 (ORL_WS32=0: tiled fp32 kernels only)
   WsGeom ws_geo;               // workgroups per net / CUs per launch of the weight-stationary kernels (orl_config::ws_one_round, ws_cus)

@@ -381,7 +381,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     }
     // With the single-output tail folded in, the backward pass of a many-row batch needs only the mask bits of this activation
     // (ws_dgrad_w0 / ws_wgrad's derived tail gradients): the activation itself then never goes to HBM.
-    const bool elide = want_tail && layer >= 1 && (fwd_only || (elide_top && !l.ens && (long)M * nz >= ws_wgrad_min_rows));
+    const bool elide = want_tail && layer >= 1 && (fwd_only || (elide_top && !l.ens && ws_wgrad_rows_ok(M, nz)));
     if (elide) w.Y = nullptr;
     const bool ws_ok = ws_fwd_supported(w, in, out);
     bool fused0 = false;
@@ -687,7 +687,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   // the tail layer's gradients ride along (*fuse_tail = true, same slabs)
   if (slabs_out && fuse_tail && dy.rank1 && with_bias && slab0 == 0 && ws_precision_ok() && !force_scalar && !l.ens &&
       dy.m.bits && bits_live.count(dy.m.bits) && out == dy.m.pitch && in_row0 == 0 && in_rows == in && X.pitch == in &&
-      (long)M * nz >= ws_wgrad_min_rows) {
+      ws_wgrad_rows_ok(M, nz)) {
     const bool derived = vals_dead.count(dy.m.p) > 0;
     WsWgradP w;
     memset(&w, 0, sizeof(w));
@@ -720,7 +720,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   // the same output-stationary kernel for a hidden layer BELOW the top one of a many-row batch: dZ is a materialised matrix (three products
   // per block instead of the rank-1 form's two, no mask / w_tail); one slab per workgroup
   if (slabs_out && !dy.rank1 && with_bias && slab0 == 0 && ws_precision_ok() && !force_scalar && !l.ens && !x_dscale && in_row0 == 0 &&
-      in_rows == in && X.pitch == in && dy.m.pitch == out && (long)M * nz >= ws_wgrad_min_rows) {
+      in_rows == in && X.pitch == in && dy.m.pitch == out && ws_wgrad_rows_ok(M, nz)) {
     WsWgradP w;
     memset(&w, 0, sizeof(w));
     w.dZ = dy.m.p; w.dz_s0 = dy.m.rs; w.dz_s1 = dy.m.cs; w.dz_pitch = dy.m.pitch;
@@ -1044,6 +1044,7 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipMemcpyAsync(scalars, sc.data(), sizeof(RunScalars) * R, hipMemcpyHostToDevice, stream));
   ORL_HIP(hipStreamSynchronize(stream));
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
+  { const char* f = getenv("ORL_WS_WGRAD_MIN_M"); if (f && atoi(f) > 0) ws_wgrad_min_m = atoi(f); }
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
