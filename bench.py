@@ -458,6 +458,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=2.0)
     ap.add_argument("--no-sides", action="store_true", help="skip fp32 / by_runs / other_configs side records")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=24.0, help="CPU work of the cpu_baseline sample (four legs share it)")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--profile-dump", default="", help="write the full per-launch-tag timing table (HIP events) to this file")
     ap.add_argument("--dataset-size", type=int, default=1_000_000)
@@ -594,7 +595,7 @@ def main():
                     g.close()
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
-        cpu = cpu_baseline() if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
+        cpu = cpu_baseline(args.cpu_baseline_seconds) if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {
             "metric": "gradient-steps/sec (CQL, batch=256)", "value": value, "unit": "gradient-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_med / args.steps * 1e3,
