@@ -893,11 +893,24 @@ __global__ void k_iql_actor_loss(IqlAP p) {
       const float g = dlogp * d / var * (1.0f - mu * mu);
       p.dmraw[(long)r * p.mraw_rs + (long)b * A + a] = g;
       amax = fmaxf(amax, fabsf(g));
-      atomicAdd(&gsig[a], dlogp * (d * d / var - 1.0f));
     }
     s += ea * lp;
   }
   s = block_sum256(s, sh);
+  // d(loss)/d(sigma_param[a]): one fixed-order block reduction per action dimension (shared-memory float atomics summed in arrival order:
+  // two runs fed identical inputs drifted apart in the last bit after ~150 steps)
+  for (int a = 0; a < A; ++a) {
+    const float ls = sp[a], sg = expf(ls), var = sg * sg;
+    float part = 0.f;
+    for (int b = threadIdx.x; b < p.B; b += 256) {
+      const float dlogp = -p.exp_a[(long)r * p.ea_rs + b] / (float)p.B;
+      const float mu = tanhf(p.mraw[(long)r * p.mraw_rs + (long)b * A + a]);
+      const float d = p.act[(long)r * p.act_rs + (long)b * p.apitch + a] - mu;
+      part += dlogp * (d * d / var - 1.0f);
+    }
+    part = block_sum256(part, sh);
+    if (threadIdx.x == 0) gsig[a] = part;
+  }
   __syncthreads();
   for (int a = threadIdx.x; a < A; a += 256) p.g_sigma[(long)r * p.gs_rs + a] = gsig[a];
   if (threadIdx.x == 0) metric_set(p.m, r, p.slot, -s / (float)p.B);

@@ -8,7 +8,7 @@ engine whose arithmetic differs from torch's in rounding only must stay inside a
 (tests/test_gpu_long_horizon.py); one whose arithmetic is coarser leaves it.
 
 Build container only (the reference does not exist on the GPU box); only arrays of numbers are stored.
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_long_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_long_golden.py [cql_halfcheetah_long] [iql_hopper_long]      (default: both)
 """
 from __future__ import annotations
 
@@ -70,23 +70,64 @@ def run(ref, eps):
     return np.array(losses, dtype=np.float64), keys
 
 
-def main():
-    ref = mg._import_reference()
-    torch.set_num_threads(4)
+IQL_CASE = "iql_hopper_long"
+
+
+def run_iql(ref, eps):
+    """the same experiment for ``IQLPolicy.learn`` (/root/reference/offlinerlkit/policy/model_free/iql.py:86-139; no noise: the step is a
+    deterministic function of the batch).  Construction as tests/golden/make_golden.py::gen_iql (run_iql.py:105-133)."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import iql as oiql
+    c, st, batches, _ = synth.iql_case_inputs(IQL_CASE)
+    cfg = oiql.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    scale = np.float32(1.0 + eps)
+
+    def pert(net):
+        return OrderedDict((k, (v * scale).astype(np.float32)) for k, v in net.items())
+    actor = ref.ActorProb(ref.MLP(od, hid), ref.DiagGaussian(hid[-1], ad, unbounded=False, conditioned_sigma=False))
+    q1, q2, v = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od, hid))
+    mg._load(actor, pert(st["actor"])); mg._load(q1, pert(st["critic_q1"])); mg._load(q2, pert(st["critic_q2"])); mg._load(v, pert(st["critic_v"]))
+    pol = ref.IQLPolicy(actor, q1, q2, v, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                        torch.optim.Adam(q1.parameters(), lr=cfg["critic_q_lr"]), torch.optim.Adam(q2.parameters(), lr=cfg["critic_q_lr"]),
+                        torch.optim.Adam(v.parameters(), lr=cfg["critic_v_lr"]), action_space=mg._ActionSpace(ad), tau=cfg["tau"],
+                        gamma=cfg["gamma"], expectile=cfg["expectile"], temperature=cfg["temperature"])
+    mg._load(pol.critic_q1_old, st["critic_q1_old"]); mg._load(pol.critic_q2_old, st["critic_q2_old"])       # (targets unperturbed)
+    pol.train()
+    losses, keys = [], None
+    for b in batches:
+        res = pol.learn(mg._tb(b))
+        keys = keys or list(res.keys())
+        losses.append([res[x] for x in keys])
+    return np.array(losses, dtype=np.float64), keys
+
+
+def generate(ref, case, runner):
     out = OrderedDict()
     t0 = time.time()
-    base, keys = run(ref, 0.0)
+    base, keys = runner(ref, 0.0)
     out["losses"] = base
     out["loss_keys"] = np.array(keys)
     out["perturbations"] = np.array(PERTURBATIONS)
     for i, eps in enumerate(PERTURBATIONS):
-        out[f"losses_perturbed{i}"], _ = run(ref, eps)
+        out[f"losses_perturbed{i}"], _ = runner(ref, eps)
         d = np.abs(out[f"losses_perturbed{i}"] - base) / np.maximum(np.abs(base), 1e-2 * np.abs(base).max(axis=0))
-        print(f"eps {eps:+.0e}: max relative deviation from the unperturbed run by step 20 / 50 / 100 / 200: "
+        print(f"{case} eps {eps:+.0e}: max relative deviation from the unperturbed run by step 20 / 50 / 100 / 200: "
               f"{d[:20].max():.2e} {d[:50].max():.2e} {d[:100].max():.2e} {d.max():.2e}")
-    path = os.path.join(HERE, f"{CASE}.npz")
+    path = os.path.join(HERE, f"{case}.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.0f} s")
+
+
+def main():
+    ref = mg._import_reference()
+    torch.set_num_threads(4)
+    which = sys.argv[1:] or [CASE, IQL_CASE]
+    if CASE in which:
+        generate(ref, CASE, run)
+    if IQL_CASE in which:
+        generate(ref, IQL_CASE, run_iql)
 
 
 if __name__ == "__main__":

@@ -230,8 +230,15 @@ def _perturbed(rng, net, s=0.01):
     return OrderedDict((n, (v + s * rng.standard_normal(v.shape)).astype(f32)) for n, v in net.items())
 
 
+# Long teacher-forced window for a second algorithm family (tests/golden/make_long_golden.py): 200 steps of the IQL hopper shape; the
+# fixture holds losses only (reference + perturbed twins), the inputs are regenerated from the seed.
+IQL_LONG_CASES = {
+    "iql_hopper_long": dict(obs_dim=11, act_dim=3, hidden=[256, 256], B=256, steps=200, seed=23, over={}),
+}
+
+
 def iql_case_inputs(case):
-    c = IQL_CASES[case]
+    c = IQL_CASES[case] if case in IQL_CASES else IQL_LONG_CASES[case]
     rng = np.random.RandomState(c["seed"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
     st = OrderedDict()

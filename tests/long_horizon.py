@@ -1,17 +1,19 @@
 """Shared pieces of the long-horizon checks (tests/test_long_horizon.py on the CPU, tests/test_gpu_long_horizon.py on the GPU): the
-200-step loss trajectory of the REAL reference and of its perturbed twins (tests/golden/make_long_golden.py -> cql_halfcheetah_long.npz),
+200-step loss trajectories of the REAL reference and of its perturbed twins (tests/golden/make_long_golden.py -> cql_halfcheetah_long.npz,
+iql_hopper_long.npz),
 and the envelope statistics every implementation is held to."""
 import os
 
 import numpy as np
 
 CASE = "cql_halfcheetah_long"
+IQL_CASE = "iql_hopper_long"          # the same experiment for IQLPolicy.learn (iql.py:86-139): a second algorithm family, no sampling noise
 HORIZONS = (20, 50, 100, 200)
 K_ENVELOPE = 4.0          # an implementation may drift from the reference up to K x as far as the reference's own one-ulp twins do
 
 
-def load():
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{CASE}.npz"), allow_pickle=False)
+def load(case=CASE):
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{case}.npz"), allow_pickle=False)
     ref = g["losses"]
     perturbed = [g[f"losses_perturbed{i}"] for i in range(len(g["perturbations"]))]
     return [str(k) for k in g["loss_keys"]], ref, perturbed
@@ -29,13 +31,21 @@ def envelope(ref, perturbed):
     return np.maximum.accumulate(d)
 
 
-def check(name, losses, ref, perturbed, report=None):
+# IQL: the twins are perturbed ONCE, by one or two ulps, and IQL amplifies slowly (1.35e-6 until step 100, then x14 per 50 steps); an
+# independent implementation injects rounding differences of that size at EVERY step, so its trajectory runs ~40 steps ahead on the same
+# growth curve.  Measured: the exact-fp32 engine AND the split engine both sit at 9 - 10 x the twin envelope at steps 100 / 150 and 4 x at
+# 200 (the numpy oracle, which mirrors torch op for op: 0.2 - 0.4 x) -- K = 12 for this fixture, and the split engine is additionally held to
+# the exact-fp32 engine's own deviation (tests/test_gpu_long_horizon.py).
+K_ENVELOPE_IQL = 12.0
+
+
+def check(name, losses, ref, perturbed, report=None, k_envelope=K_ENVELOPE):
     d = np.maximum.accumulate(deviation(losses, ref))
     env = envelope(ref, perturbed)
     rows = []
     for T in HORIZONS:
         rows.append((T, float(d[T - 1]), float(env[T - 1])))
-        assert d[T - 1] <= K_ENVELOPE * env[T - 1], (name, "steps", T, "deviation", d[T - 1], "reference envelope", env[T - 1])
+        assert d[T - 1] <= k_envelope * env[T - 1], (name, "steps", T, "deviation", d[T - 1], "reference envelope", env[T - 1])
     assert d[19] < 1e-4, (name, "the 1e-4 gate over the first 20 teacher-forced steps", d[19])
     line = f"{name}: max relative loss deviation from the reference by step " + ", ".join(f"{T}: {a:.2e} (envelope {b:.2e})" for T, a, b in rows)
     print(line)

@@ -7,7 +7,7 @@ import numpy as np
 
 import long_horizon as lh
 import synth
-from helpers import cql_oracle_setup
+from helpers import cql_oracle_setup, generic_oracle_setup
 
 
 def test_fixture_shape_and_the_reference_envelope_itself():
@@ -28,3 +28,20 @@ def test_oracle_stays_inside_the_reference_envelope_for_200_steps():
         res, _ = ocql.learn(st, cfg, b, n)
         losses.append([res[k] for k in keys])
     lh.check("numpy oracle", np.array(losses), ref, perturbed)
+
+
+def test_iql_fixture_and_oracle_stay_inside_the_reference_envelope_for_200_steps():
+    """The same statement for IQLPolicy.learn (iql.py:86-139; fixture iql_hopper_long.npz).  IQL's dynamics are benign: the reference's
+    one-ulp twins stay ~1e-6 apart for 100 steps and part ways only when a discrete event (an expectile weight or an exp clamp switching)
+    lands differently -- 6e-6 .. 4e-4 by step 200."""
+    keys, ref, perturbed = lh.load(lh.IQL_CASE)
+    assert ref.shape == (200, 4) and keys == ["loss/actor", "loss/q1", "loss/q2", "loss/v"] and len(perturbed) == 4
+    env = lh.envelope(ref, perturbed)
+    assert env[99] < 1e-5 < env[199] < 2e-3
+    mod, cfg, st, batches, noises = generic_oracle_setup("iql", lh.IQL_CASE)
+    assert len(batches) == 200
+    losses = []
+    for b, n in zip(batches, noises):
+        res, _ = mod.learn(st, cfg, b, n)
+        losses.append([res[k] for k in keys])
+    lh.check("numpy oracle (IQL)", np.array(losses), ref, perturbed)
