@@ -123,6 +123,32 @@ def test_many_runs_split_bf16_follows_the_oracle(algo, R):
         eng.close()
 
 
+@pytest.mark.parametrize("R", [2, 16])
+@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
+def test_identical_runs_stay_bit_identical(algo, precision, R):
+    """No arrival-order arithmetic anywhere in a step: the runs of one engine, given identical parameters, batches and noise, report
+    bit-identical metrics at every step and hold bit-identical parameters at the end (the reference on the CPU is deterministic in the
+    same sense).  This is what caught `k_iql_actor_loss`'s shared-memory float atomics (the runs parted in the last bit after ~150 steps);
+    two and sixteen runs per engine take different kernel families (one-launch forward / tiled vs weight-stationary)."""
+    case = _full_size_case(algo)
+    eng, mod, cfg, st, batches, noises = make_engine(algo, case, n_runs=R, precision=precision)
+    try:
+        for k, (b, n) in enumerate(zip(batches, noises)):
+            nl = noise_list(algo, n)
+            m = eng.step({kk: np.stack([v] * R) for kk, v in b.items()}, [np.stack([v] * R) for v in nl] if nl is not None else [])
+            for r in range(1, R):
+                assert np.array_equal(m[0], m[r]), (algo, k, r, m[0], m[r])
+        for nm, nid in NET_IDS[algo].items():
+            a = eng.get_net(0, nid)
+            for r in (1, R - 1):
+                b1 = eng.get_net(r, nid)
+                for pn in a:
+                    assert np.array_equal(a[pn], b1[pn]), (algo, nm, pn, r)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("case", list(synth.IQL_CASES))
 def test_iql_step(case):
     run_case("iql", case, (("q1", "q1", "step0/q1"), ("v", "v", "step0/v"), ("target_q", "target_q", None), ("exp_a", "exp_a", None)))
