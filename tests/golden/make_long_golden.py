@@ -8,7 +8,7 @@ engine whose arithmetic differs from torch's in rounding only must stay inside a
 (tests/test_gpu_long_horizon.py); one whose arithmetic is coarser leaves it.
 
 Build container only (the reference does not exist on the GPU box); only arrays of numbers are stored.
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_long_golden.py [cql_halfcheetah_long] [iql_hopper_long]      (default: both)
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_long_golden.py [cql_halfcheetah_long] [iql_hopper_long] [td3bc_halfcheetah_long] [edac_walker2d_long]   (default: all)
 """
 from __future__ import annotations
 
@@ -103,6 +103,82 @@ def run_iql(ref, eps):
     return np.array(losses, dtype=np.float64), keys
 
 
+TD3BC_CASE = "td3bc_halfcheetah_long"
+EDAC_CASE = "edac_walker2d_long"
+
+
+def run_td3bc(ref, eps):
+    """``TD3BCPolicy.learn`` (/root/reference/offlinerlkit/policy/model_free/td3bc.py:83-124), target-policy noise teacher-forced;
+    construction as tests/golden/make_golden.py::gen_td3bc.  The actor's loss is reported on its update steps only (every 2nd)."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import td3bc as otd
+    c, st, batches, noises = synth.td3bc_case_inputs(TD3BC_CASE)
+    cfg = otd.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
+    scale = np.float32(1.0 + eps)
+
+    def pert(net):
+        return OrderedDict((k, (v * scale).astype(np.float32)) for k, v in net.items())
+    actor = ref.Actor(ref.MLP(od, hid), ad, max_action=cfg["max_action"])
+    c1, c2 = ref.Critic(ref.MLP(od + ad, hid)), ref.Critic(ref.MLP(od + ad, hid))
+    mg._load(actor, pert(st["actor"])); mg._load(c1, pert(st["critic1"])); mg._load(c2, pert(st["critic2"]))
+    pol = ref.TD3BCPolicy(actor, c1, c2, torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"]),
+                          torch.optim.Adam(c1.parameters(), lr=cfg["critic_lr"]), torch.optim.Adam(c2.parameters(), lr=cfg["critic_lr"]),
+                          tau=cfg["tau"], gamma=cfg["gamma"], max_action=cfg["max_action"], policy_noise=cfg["policy_noise"],
+                          noise_clip=cfg["noise_clip"], update_actor_freq=cfg["update_actor_freq"], alpha=cfg["alpha"], scaler=None)
+    mg._load(pol.actor_old, st["actor_old"]); mg._load(pol.critic1_old, st["critic1_old"]); mg._load(pol.critic2_old, st["critic2_old"])
+    pol.train()
+    feeder = mg.NoiseFeeder(); feeder.install()
+    losses, keys = [], None
+    try:
+        for b, n in zip(batches, noises):
+            feeder.normal_q = [n["eps_target"]]
+            res = pol.learn(mg._tb(b))
+            keys = keys or list(res.keys())
+            losses.append([res[x] for x in keys])
+    finally:
+        feeder.uninstall()
+    return np.array(losses, dtype=np.float64), keys
+
+
+def run_edac(ref, eps):
+    """``EDACPolicy.learn`` (/root/reference/offlinerlkit/policy/model_free/edac.py:88-166) at the walker2d shape (10 critics,
+    [256, 256, 256], eta 5); construction as tests/golden/make_golden.py::gen_edac."""
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from oracle import edac as oed
+    c, st, batches, noises = synth.edac_case_inputs(EDAC_CASE)
+    cfg = oed.default_cfg(c["obs_dim"], c["act_dim"])
+    cfg.update(hidden=c["hidden"]); cfg.update(c["over"])
+    od, ad, hid, K = c["obs_dim"], c["act_dim"], c["hidden"], cfg["num_critics"]
+    scale = np.float32(1.0 + eps)
+
+    def pert(net):
+        return OrderedDict((k, (v * scale).astype(np.float32)) for k, v in net.items())
+    actor = ref.ActorProb(ref.MLP(od, hid), ref.TanhDiagGaussian(hid[-1], ad, unbounded=True, conditioned_sigma=True))
+    critics = ref.EnsembleCritic(od, ad, hid, num_ensemble=K)
+    mg._load(actor, pert(st["actor"])); mg._load(critics, pert(st["critics"]))
+    aopt = torch.optim.Adam(actor.parameters(), lr=cfg["actor_lr"])
+    copt = torch.optim.Adam(critics.parameters(), lr=cfg["critic_lr"])
+    log_alpha = torch.tensor(st["log_alpha"].copy(), requires_grad=True)
+    alpha = (cfg["target_entropy"], log_alpha, torch.optim.Adam([log_alpha], lr=cfg["alpha_lr"]))
+    pol = ref.EDACPolicy(actor, critics, aopt, copt, tau=cfg["tau"], gamma=cfg["gamma"], alpha=alpha,
+                         max_q_backup=cfg["max_q_backup"], deterministic_backup=cfg["deterministic_backup"], eta=cfg["eta"])
+    mg._load(pol.critics_old, st["critics_old"])       # (targets unperturbed)
+    pol.train()
+    feeder = mg.NoiseFeeder(); feeder.install()
+    losses, keys = [], None
+    try:
+        for b, n in zip(batches, noises):
+            feeder.normal_q = [n["eps_actor"], n["eps_next"]]
+            res = pol.learn(mg._tb(b))
+            keys = keys or list(res.keys())
+            losses.append([res[x] for x in keys])
+    finally:
+        feeder.uninstall()
+    return np.array(losses, dtype=np.float64), keys
+
+
 def generate(ref, case, runner):
     out = OrderedDict()
     t0 = time.time()
@@ -123,11 +199,11 @@ def generate(ref, case, runner):
 def main():
     ref = mg._import_reference()
     torch.set_num_threads(4)
-    which = sys.argv[1:] or [CASE, IQL_CASE]
-    if CASE in which:
-        generate(ref, CASE, run)
-    if IQL_CASE in which:
-        generate(ref, IQL_CASE, run_iql)
+    table = ((CASE, run), (IQL_CASE, run_iql), (TD3BC_CASE, run_td3bc), (EDAC_CASE, run_edac))
+    which = sys.argv[1:] or [c for c, _ in table]
+    for case, runner in table:
+        if case in which:
+            generate(ref, case, runner)
 
 
 if __name__ == "__main__":

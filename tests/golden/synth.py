@@ -256,8 +256,14 @@ def iql_case_inputs(case):
     return c, st, batches, noises
 
 
+# (long teacher-forced windows, as IQL_LONG_CASES: tests/golden/make_long_golden.py)
+TD3BC_LONG_CASES = {
+    "td3bc_halfcheetah_long": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, steps=200, seed=33, over={}),
+}
+
+
 def td3bc_case_inputs(case):
-    c = TD3BC_CASES[case]
+    c = TD3BC_CASES[case] if case in TD3BC_CASES else TD3BC_LONG_CASES[case]
     rng = np.random.RandomState(c["seed"])
     od, ad, hid = c["obs_dim"], c["act_dim"], c["hidden"]
     st = OrderedDict()
@@ -282,8 +288,13 @@ EDAC_CASES = {
 }
 
 
+EDAC_LONG_CASES = {
+    "edac_walker2d_long": dict(obs_dim=17, act_dim=6, hidden=[256, 256, 256], B=256, steps=200, seed=43, over=dict(num_critics=10, eta=5.0)),
+}
+
+
 def edac_case_inputs(case):
-    c = EDAC_CASES[case]
+    c = EDAC_CASES[case] if case in EDAC_CASES else EDAC_LONG_CASES[case]
     rng = np.random.RandomState(c["seed"])
     od, ad, hid, K = c["obs_dim"], c["act_dim"], c["hidden"], c["over"]["num_critics"]
     st = OrderedDict()

@@ -1,6 +1,6 @@
 """Shared pieces of the long-horizon checks (tests/test_long_horizon.py on the CPU, tests/test_gpu_long_horizon.py on the GPU): the
 200-step loss trajectories of the REAL reference and of its perturbed twins (tests/golden/make_long_golden.py -> cql_halfcheetah_long.npz,
-iql_hopper_long.npz),
+iql_hopper_long.npz, td3bc_halfcheetah_long.npz, edac_walker2d_long.npz),
 and the envelope statistics every implementation is held to."""
 import os
 
@@ -37,6 +37,12 @@ def envelope(ref, perturbed):
 # 200 (the numpy oracle, which mirrors torch op for op: 0.2 - 0.4 x) -- K = 12 for this fixture, and the split engine is additionally held to
 # the exact-fp32 engine's own deviation (tests/test_gpu_long_horizon.py).
 K_ENVELOPE_IQL = 12.0
+# fixtures of the other algorithm families: (algorithm, case, K).  TD3+BC's twins are 2e-7 .. 1.5e-6 apart for 50 steps and grow fast after
+# that (2e-5 at 100, 1.5e-3 at 200); EDAC is chaotic from the start like CQL (5e-5 at 20 steps, 1e-3 at 200).  Both engines measured at
+# <= 1.05 x the envelope on both: K = 4 as for CQL.
+TD3BC_CASE = "td3bc_halfcheetah_long"
+EDAC_CASE = "edac_walker2d_long"
+OTHER_CASES = (("iql", IQL_CASE, K_ENVELOPE_IQL), ("td3bc", TD3BC_CASE, K_ENVELOPE), ("edac", EDAC_CASE, K_ENVELOPE))
 
 
 def check(name, losses, ref, perturbed, report=None, k_envelope=K_ENVELOPE):

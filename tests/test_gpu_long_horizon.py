@@ -35,34 +35,38 @@ def test_engine_stays_inside_the_reference_envelope_for_200_steps(precision):
         eng.close()
 
 
-def test_iql_engines_stay_inside_the_reference_envelope_for_200_steps():
-    """IQL hopper shape, 200 teacher-forced steps (iql.py:86-139; tests/golden/iql_hopper_long.npz), both engine precisions in one test:
-    each inside K = 12 x the reference's one-ulp twin envelope (tests/long_horizon.py says why 12 and not 4 here: the exact-fp32 engine needs
-    it as much as the split engine does), the plain 1e-4 gate over the first 20 steps, the two runs of an engine bit-identical at every step
-    (no arrival-order arithmetic anywhere in the step), and the split engine no further from the reference than 2 x the exact-fp32 engine."""
+@pytest.mark.parametrize("algo,case,k_env", lh.OTHER_CASES)
+def test_other_algorithms_stay_inside_the_reference_envelope_for_200_steps(algo, case, k_env):
+    """IQL (hopper shape, iql.py:86-139), TD3+BC (halfcheetah shape, td3bc.py:83-124) and EDAC (walker2d shape, 10 critics, eta 5,
+    edac.py:88-166): 200 teacher-forced steps against the REAL reference's loss trajectory, both engine precisions in one test -- each inside
+    K x the reference's one-ulp twin envelope (K = 4; tests/long_horizon.py says why K = 12 for IQL: the exact-fp32 engine needs it as much
+    as the split engine does), the plain 1e-4 gate over the first 20 steps, the two runs of an engine bit-identical at every step (no
+    arrival-order arithmetic anywhere in the step), and the split engine no further from the reference than 2 x the exact-fp32 engine or the twins' own spread, whichever is larger."""
     from offlinerlkit import _engine
-    keys, ref, perturbed = lh.load(lh.IQL_CASE)
+    keys, ref, perturbed = lh.load(case)
     R = 2
     synth = ta.synth
+    table, long_table = getattr(synth, f"{algo.upper()}_CASES"), getattr(synth, f"{algo.upper()}_LONG_CASES")
     dev = {}
     for precision in (0, 1):
-        # (IQL_LONG_CASES is not in IQL_CASES: the engine builder looks the shape up through synth's case table)
-        synth.IQL_CASES[lh.IQL_CASE] = synth.IQL_LONG_CASES[lh.IQL_CASE]
+        table[case] = long_table[case]          # (the engine builder looks the shape up through synth's case table)
         try:
-            eng, mod, cfg, st, batches, noises = ta.make_engine("iql", lh.IQL_CASE, n_runs=R, precision=precision)
+            eng, mod, cfg, st, batches, noises = ta.make_engine(algo, case, n_runs=R, precision=precision)
         finally:
-            del synth.IQL_CASES[lh.IQL_CASE]
+            del table[case]
         assert eng.metric_names == keys
         try:
             losses = []
-            for k, b in enumerate(batches):
-                m = eng.step({kk: np.repeat(v[None], R, 0) for kk, v in b.items()}, None)
-                assert np.array_equal(m[0], m[1]), (precision, k, m[0], m[1])
+            for k, (b, n) in enumerate(zip(batches, noises)):
+                nl = ta.noise_list(algo, n)
+                m = eng.step({kk: np.stack([v] * R) for kk, v in b.items()}, [np.stack([v] * R) for v in nl] if nl is not None else [])
+                assert np.array_equal(m[0], m[1]), (algo, precision, k, m[0], m[1])
                 losses.append(m[0])
-            what = "exact-fp32 engine (IQL)" if precision == 0 else f"split engine (IQL, {_engine.split_bits()}-bit operands)"
-            rows = lh.check(what, np.array(losses, np.float64), ref, perturbed, k_envelope=lh.K_ENVELOPE_IQL)
+            what = f"exact-fp32 engine ({algo})" if precision == 0 else f"split engine ({algo}, {_engine.split_bits()}-bit operands)"
+            rows = lh.check(what, np.array(losses, np.float64), ref, perturbed, k_envelope=k_env)
             dev[precision] = {T: d for T, d, _ in rows}
+            env = {T: e for T, _, e in rows}
         finally:
             eng.close()
-    for T in lh.HORIZONS:
-        assert dev[1][T] <= 2.0 * dev[0][T] + 1e-6, (T, dev[1][T], dev[0][T])
+    for T in lh.HORIZONS:        # (an engine that happens to track torch's rounding can sit far below the envelope: the twins' own spread is the floor)
+        assert dev[1][T] <= max(2.0 * dev[0][T], env[T]) + 1e-6, (algo, T, dev[1][T], dev[0][T], env[T])

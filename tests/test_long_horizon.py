@@ -4,6 +4,7 @@ and 5e-4 .. 8e-4 by step 200 (tests/golden/cql_halfcheetah_long.npz: four pertur
 statement that can be made is distributional: an implementation whose arithmetic differs from torch's in rounding only stays within a
 small multiple (K = 4) of that envelope at steps 20 / 50 / 100 / 200.  Here: the numpy oracle; on the GPU: both engine precisions."""
 import numpy as np
+import pytest
 
 import long_horizon as lh
 import synth
@@ -30,18 +31,19 @@ def test_oracle_stays_inside_the_reference_envelope_for_200_steps():
     lh.check("numpy oracle", np.array(losses), ref, perturbed)
 
 
-def test_iql_fixture_and_oracle_stay_inside_the_reference_envelope_for_200_steps():
-    """The same statement for IQLPolicy.learn (iql.py:86-139; fixture iql_hopper_long.npz).  IQL's dynamics are benign: the reference's
-    one-ulp twins stay ~1e-6 apart for 100 steps and part ways only when a discrete event (an expectile weight or an exp clamp switching)
-    lands differently -- 6e-6 .. 4e-4 by step 200."""
-    keys, ref, perturbed = lh.load(lh.IQL_CASE)
-    assert ref.shape == (200, 4) and keys == ["loss/actor", "loss/q1", "loss/q2", "loss/v"] and len(perturbed) == 4
+@pytest.mark.parametrize("algo,case,k_env", lh.OTHER_CASES)
+def test_other_algorithms_oracle_stays_inside_the_reference_envelope_for_200_steps(algo, case, k_env):
+    """The same statement for IQLPolicy.learn (iql.py:86-139), TD3BCPolicy.learn (td3bc.py:83-124) and EDACPolicy.learn (edac.py:88-166;
+    walker2d shape, 10 critics, eta 5).  IQL and TD3+BC amplify slowly: the reference's one-ulp twins stay ~1e-6 apart for 50 - 100 steps
+    and then grow an order of magnitude per 50 steps; EDAC is chaotic from the start like CQL."""
+    keys, ref, perturbed = lh.load(case)
+    assert ref.shape == (200, len(keys)) and len(perturbed) == 4
     env = lh.envelope(ref, perturbed)
-    assert env[99] < 1e-5 < env[199] < 2e-3
-    mod, cfg, st, batches, noises = generic_oracle_setup("iql", lh.IQL_CASE)
+    assert env[19] < 1e-4 < env[199] < 5e-3
+    mod, cfg, st, batches, noises = generic_oracle_setup(algo, case)
     assert len(batches) == 200
     losses = []
     for b, n in zip(batches, noises):
         res, _ = mod.learn(st, cfg, b, n)
         losses.append([res[k] for k in keys])
-    lh.check("numpy oracle (IQL)", np.array(losses), ref, perturbed)
+    lh.check(f"numpy oracle ({algo})", np.array(losses), ref, perturbed, k_envelope=k_env)
