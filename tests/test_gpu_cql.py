@@ -242,6 +242,31 @@ def test_cql_fp32_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
         eng4.close(); eng1.close()
 
 
+@pytest.mark.parametrize("R", [2, 16, 96])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_identical_cql_runs_stay_bit_identical(precision, R):
+    """No arrival-order arithmetic in the CQL step either (one-launch loss with its last-arriver reduction, split-K slabs summed by Adam in
+    slab order, weight-stationary kernels with one slab per workgroup): runs given identical parameters, batches and noise report
+    bit-identical metrics at every step and end with bit-identical parameters -- at 2 runs (one-launch forwards, tiled small passes), 16
+    and 96 runs (bench.py's engine)."""
+    case = "cql_halfcheetah"
+    eng, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    steps = len(batches) if R < 96 else 4
+    try:
+        for k, (b, n) in enumerate(zip(batches[:steps], noises[:steps])):
+            m = eng.step(lead(b, R), lead(noise_list(n), R))
+            for r in range(1, R):
+                assert np.array_equal(m[0], m[r]), (k, r, m[0], m[r])
+        for nm in ("critic1", "critic2", "actor"):
+            a = eng.get_net(0, NETS[nm])
+            for r in (1, R - 1):
+                b1 = eng.get_net(r, NETS[nm])
+                for pn in a:
+                    assert np.array_equal(a[pn], b1[pn]), (nm, pn, r)
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("precision", [1, 0])
 def test_small_forward_kernel_matches_tiled_launches(monkeypatch, precision):
     """Few runs per engine: every 256-row forward pass (actor, critic(s, pi(s)), actor on [s; s'], target critics) is ONE launch of
