@@ -29,6 +29,39 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
   const long so = z0 * p.o_s0 + (long)blockIdx.x * p.o_ks;
   float* dW = p.dW + so + z1 * p.o_s1w;
   float* db = p.db + so + z1 * p.o_s1b;
+  // ---- MODE 2, first: the tail gradient's partial sums (they need the accumulators and W1 only) BEFORE the slab stores -- vmcnt returns
+  // in order, so a load issued behind 128 stores waits for all of them.  The W1 elements are fetched 16 at a time (one exposed L2 latency
+  // per two k blocks; one load -> wait -> multiply round trip per element cost ~40 us per workgroup), and the 16 lanes of a row group are
+  // summed with DPP row operations on the vector ALU instead of four dependent ds_bpermute round trips per element.
+  if (MODE == 2) {
+    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
+    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
+#pragma unroll
+    for (int kb2 = 0; kb2 < 16; kb2 += 2) {
+      float wa[2][4], wb[2][4];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * (kb2 + h) + 4 * lq + r;
+          wa[h][r] = W1g[(long)o * WS_N + ncol0 + li];
+          wb[h][r] = W1g[(long)o * WS_N + ncol0 + 16 + li];
+        }
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = 16 * (kb2 + h) + 4 * lq + r;
+          float t = (wa[h][r] * acc[kb2 + h][0][r] + wb[h][r] * acc[kb2 + h][1][r]) * inv;
+          // row sum over the 16 lanes li: quad pairs, quads, half-row mirror, row mirror (every lane ends with the full sum)
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, false));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, false));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x140, 0xF, 0xF, false));
+          if (li == 0) red[wave * WS_K + o] = t;
+        }
+    }
+  }
   if (MODE == 3) {                                   // plain dZ: the accumulators are the gradient (no rank-1 factor)
 #pragma unroll
     for (int kb = 0; kb < 16; ++kb)
@@ -55,19 +88,9 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
       for (int r = 0; r < 4; ++r) dW[(long)(16 * kb + 4 * lq + r) * WS_N + ncol0 + 16 * nb + li] = (w4[r] * inv) * acc[kb][nb][r];
   }
   if (MODE == 2) {
-    // dw_tail partial of this slab: every lane folds its two input columns of each of its 64 output units, the 16 lanes of a
-    // group and then the 8 waves (= all 256 input columns) are summed in a fixed order
-    const float* __restrict__ W1g = p.W1 + z0 * p.w1_s0 + z1 * p.w1_s1;
-    float* red = ws_smem;                                            // the images are dead after the loop's last barrier
-#pragma unroll
-    for (int kb = 0; kb < 16; ++kb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = 16 * kb + 4 * lq + r;
-        float t = (W1g[(long)o * WS_N + ncol0 + li] * acc[kb][0][r] + W1g[(long)o * WS_N + ncol0 + 16 + li] * acc[kb][1][r]) * inv;
-        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-        if (li == 0) red[wave * WS_K + o] = t;
-      }
+    // dw_tail partial of this slab: every lane folded its two input columns of each of its 64 output units above (before the slab
+    // stores); the 8 waves (= all 256 input columns) are summed in a fixed order
+    float* red = ws_smem;
     if (li == 0) {
 #pragma unroll
       for (int x = 0; x < 2; ++x)
