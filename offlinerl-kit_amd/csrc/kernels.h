@@ -1198,29 +1198,47 @@ __global__ void k_edac_t0(EdacT0P p) {
   const float* w = p.W + z0 * p.w_rs + z1 * p.w_cs;
   const float* gbase = p.gamma + z0 * p.g_rs + z1 * p.g_cs;
   float* out = p.out + z0 * p.o_rs + z1 * p.o_cs;
+  // The 8 x 8 gamma values of the wave's row block are ONE vector load (lane l holds row l / 8, action l % 8; clamped index, factor 0
+  // beyond A), read back below with v_readlane -- as wave-uniform scalars each of them was its own load -> wait -> readfirstlane round
+  // trip (80 per thread in the first version).  Loaded OUTSIDE the column loop: every lane must hold its value, also the lanes whose columns
+  // lie beyond N.
+  static_assert(EDAC_T0_RB * EDAC_T0_AMAX == 64, "one lane per (row, action) of the block");
+  const int b0 = EDAC_T0_RB * (blockIdx.x * (blockDim.x >> 6) + wave);
+  const int gi = lane >> 3, ga = lane & 7, gb = b0 + gi < p.B ? b0 + gi : p.B - 1;
+  float gl = (ga < p.A ? 1.f : 0.f) * gbase[(long)gb * p.gpitch + (ga < p.A ? ga : p.A - 1)];
+  asm volatile("" : "+v"(gl));      // materialise it HERE, in every lane: the optimiser otherwise sinks the load into the column loop, where the
+                                    // lanes beyond N are masked off -- and v_readlane below would read their stale registers
   for (int j = 4 * lane; j < p.N; j += 256) {
     f4 wr[EDAC_T0_AMAX];
 #pragma unroll
-    for (int a = 0; a < EDAC_T0_AMAX; ++a) wr[a] = a < p.A ? *(const f4*)&w[(long)a * p.wpitch + j] : (f4){0.f, 0.f, 0.f, 0.f};
-    const int b0 = EDAC_T0_RB * (blockIdx.x * (blockDim.x >> 6) + wave);
+    for (int a = 0; a < EDAC_T0_AMAX; ++a) wr[a] = *(const f4*)&w[(long)(a < p.A ? a : p.A - 1) * p.wpitch + j];      // (rows >= A: their gamma factor is 0)
+    // every load of the row block is issued before the first use
+    unsigned int mw[EDAC_T0_RB];
+    f4 hv[EDAC_T0_RB];
+    const bool use_bits = p.bits != nullptr;                       // uniform
+#pragma unroll
+    for (int i = 0; i < EDAC_T0_RB; ++i) {
+      const int b = b0 + i < p.B ? b0 + i : p.B - 1;
+      mw[i] = use_bits ? (p.bits + z0 * p.b_rs + z1 * p.b_cs)[(long)b * p.bg + (j >> 5)] >> (j & 31) : 0u;
+    }
+    if (!use_bits) {
+#pragma unroll
+      for (int i = 0; i < EDAC_T0_RB; ++i) {
+        const int b = b0 + i < p.B ? b0 + i : p.B - 1;
+        hv[i] = *(const f4*)&(p.h0 + z0 * p.h_rs + z1 * p.h_cs)[(long)b * p.hpitch + j];
+        mw[i] = (hv[i][0] > 0.f ? 1u : 0u) | (hv[i][1] > 0.f ? 2u : 0u) | (hv[i][2] > 0.f ? 4u : 0u) | (hv[i][3] > 0.f ? 8u : 0u);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < EDAC_T0_RB; ++i) {
       const int b = b0 + i;
-      if (b >= p.B) break;
-      const float* g = gbase + (long)b * p.gpitch;             // wave-uniform: scalar loads
       f4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int a = 0; a < EDAC_T0_AMAX; ++a) if (a < p.A) acc += g[a] * wr[a];
-      if (p.bits) {
-        const unsigned int m = (p.bits + z0 * p.b_rs + z1 * p.b_cs)[(long)b * p.bg + (j >> 5)] >> (j & 31);
+      for (int a = 0; a < EDAC_T0_AMAX; ++a)
+        acc += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gl), 8 * i + a)) * wr[a];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = ((m >> r) & 1u) ? acc[r] : 0.f;
-      } else {
-        const f4 h = *(const f4*)&(p.h0 + z0 * p.h_rs + z1 * p.h_cs)[(long)b * p.hpitch + j];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = h[r] > 0.f ? acc[r] : 0.f;
-      }
-      *(f4*)&out[(long)b * p.opitch + j] = acc;
+      for (int r = 0; r < 4; ++r) acc[r] = ((mw[i] >> r) & 1u) ? acc[r] : 0.f;
+      if (b < p.B) *(f4*)&out[(long)b * p.opitch + j] = acc;
     }
   }
 }

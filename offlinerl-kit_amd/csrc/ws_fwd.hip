@@ -87,11 +87,16 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     for (int cb = 0; cb < WS_CB; ++cb) {
       const int n = ncol0 + 16 * cb + li;
       f32x4 a, b;
+      // clamped addresses and 0 / 1 factors, not guarded loads (each guard is a branch with its own wait: twelve serialized round trips
+      // per workgroup and problem).  0 * w is exact for finite weights; a diverged run's Inf / NaN would spread into the zero columns.
+      const float bn = b0g[n];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k0 = 8 * lq + j, k1 = k0 + 4;
-        a[j] = k0 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k0 * p.w0_sk] : (k0 == p.in0 ? b0g[n] : 0.f);
-        b[j] = k1 < p.in0 ? W0g[(long)n * p.w0_sn + (long)k1 * p.w0_sk] : (k1 == p.in0 ? b0g[n] : 0.f);
+        const float w0 = W0g[(long)n * p.w0_sn + (long)(k0 < p.in0 ? k0 : p.in0 - 1) * p.w0_sk];
+        const float w1 = W0g[(long)n * p.w0_sn + (long)(k1 < p.in0 ? k1 : p.in0 - 1) * p.w0_sk];
+        a[j] = (k0 < p.in0 ? 1.f : 0.f) * w0 + (k0 == p.in0 ? 1.f : 0.f) * bn;
+        b[j] = (k1 < p.in0 ? 1.f : 0.f) * w1 + (k1 == p.in0 ? 1.f : 0.f) * bn;
       }
       if constexpr (!F32) ws_split8(a, b, b0h[cb], b0l[cb]);
       if constexpr (F32) {
@@ -100,7 +105,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int k = 16 * t + 4 * lq + j;
-            b0w[cb][t][j] = k < p.in0 ? W0g[(long)n * p.w0_sn + (long)k * p.w0_sk] : (k == p.in0 ? b0g[n] : 0.f);
+            const float w = W0g[(long)n * p.w0_sn + (long)(k < p.in0 ? k : p.in0 - 1) * p.w0_sk];
+            b0w[cb][t][j] = (k < p.in0 ? 1.f : 0.f) * w + (k == p.in0 ? 1.f : 0.f) * bn;
           }
       }
     }
