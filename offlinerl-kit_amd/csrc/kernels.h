@@ -726,15 +726,27 @@ __global__ void k_adam(AdamP p) {
     f4 gs;
     if (nslab == 1) gs = *(const f4*)&g[i0];
     else {
-      f4 q[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // fixed order, four partial sums
+      // fixed order, eight partial sums; eight slabs requested per round trip (a net with few runs per engine has up to 32 slabs of a
+      // many-row weight gradient: 4 at a time were 8 exposed latencies of the launch)
+      f4 q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = (f4){0.f, 0.f, 0.f, 0.f};
       int s = 0;
-      for (; s + 4 <= nslab; s += 4) {
+      for (; s + 8 <= nslab; s += 8) {
+        f4 t[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) q[j] += *(const f4*)&g[i0 + (long)(s + j) * p.g_ks];
+        for (int j = 0; j < 8; ++j) t[j] = *(const f4*)&g[i0 + (long)(s + j) * p.g_ks];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] += t[j];
       }
+      if (s < nslab) {                                   // (uniform: the slab count belongs to the tensor group)
+        f4 t[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) if (s + j < nslab) q[j] += *(const f4*)&g[i0 + (long)(s + j) * p.g_ks];
-      gs = (q[0] + q[1]) + (q[2] + q[3]);
+        for (int j = 0; j < 8; ++j) t[j] = *(const f4*)&g[i0 + (long)(s + j < nslab ? s + j : nslab - 1) * p.g_ks];      // clamped, not guarded
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] += (s + j < nslab ? 1.f : 0.f) * t[j];
+      }
+      gs = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     }
     f4 m = *(const f4*)&p.m[o + i0], v = *(const f4*)&p.v[o + i0], w = *(const f4*)&p.params[o + i0];
 #pragma unroll
