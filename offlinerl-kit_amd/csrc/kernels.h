@@ -1046,16 +1046,23 @@ struct Td3ActorBwdP {
   const float* act; long act_rs; int apitch;
   float* dmraw; long dm_rs;
   int B, A; float max_action;
+  float* gs_out;                                   // split precision: dynamic scale of the actor's backward pass [R], or null
 };
+// one workgroup per run (B * A elements: a few per thread), so that the seed kernel can publish the backward pass's gradient scale itself
 __global__ void k_td3_actor_bwd(Td3ActorBwdP p) {
-  const int r = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= p.B * p.A) return;
-  const int b = t / p.A, a = t - b * p.A;
-  const float ap = p.xa[(long)r * p.xa_rs + (long)b * p.XP + p.od + a];
-  const float da = p.dxa[(long)r * p.dxa_rs + (long)b * p.dxa_pitch + a] + 2.0f * (ap - p.act[(long)r * p.act_rs + (long)b * p.apitch + a]) / (float)(p.B * p.A);
-  const float th = ap / p.max_action;
-  p.dmraw[(long)r * p.dm_rs + t] = da * p.max_action * (1.0f - th * th);
+  __shared__ float sh[4];
+  const int r = blockIdx.x;
+  float amax = 0.f;
+  for (int t = threadIdx.x; t < p.B * p.A; t += 256) {
+    const int b = t / p.A, a = t - b * p.A;
+    const float ap = p.xa[(long)r * p.xa_rs + (long)b * p.XP + p.od + a];
+    const float da = p.dxa[(long)r * p.dxa_rs + (long)b * p.dxa_pitch + a] + 2.0f * (ap - p.act[(long)r * p.act_rs + (long)b * p.apitch + a]) / (float)(p.B * p.A);
+    const float th = ap / p.max_action;
+    const float g = da * p.max_action * (1.0f - th * th);
+    p.dmraw[(long)r * p.dm_rs + t] = g;
+    amax = fmaxf(amax, fabsf(g));
+  }
+  grad_scale_publish(amax, sh, p.gs_out, r);
 }
 
 // ================================================================================================
