@@ -64,6 +64,13 @@ PRESETS = {
     # BASELINE config 5: 8 seeds x 8 tasks, one task (its own synthetic buffer) and its 8 seeds per GPU, one engine
     "config5": dict(runs_per_gpu=8, engines_per_gpu=1),
 }
+# ... and its 8 D4RL-mujoco tasks, one per GPU (rank r trains task r % 8): observation / action widths and transition counts of the D4RL v2
+# datasets (halfcheetah / walker2d: obs 17, act 6; hopper: obs 11, act 3 -- the critic input is 14 columns wide there, the actor head 6)
+CONFIG5_TASKS = [
+    ("halfcheetah-medium-v2", 17, 6, 1_000_000), ("hopper-medium-v2", 11, 3, 1_000_000), ("walker2d-medium-v2", 17, 6, 1_000_000),
+    ("halfcheetah-medium-replay-v2", 17, 6, 202_000), ("hopper-medium-replay-v2", 11, 3, 402_000), ("walker2d-medium-replay-v2", 17, 6, 302_000),
+    ("halfcheetah-medium-expert-v2", 17, 6, 2_000_000), ("hopper-medium-expert-v2", 11, 3, 2_000_000),
+]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -120,12 +127,13 @@ def make_dataset(seed, n=1_000_000, od=OBS, ad=ACT):
     return bw.make_dataset(seed, n, od, ad)
 
 
-def make_cql_engines(E, R, device, precision, seed0, buf, one_round=None):
+def make_cql_engines(E, R, device, precision, seed0, buf, one_round=None, od=OBS, ad=ACT):
     """E engines x R runs of the headline workload on one GPU.  With several engines per GPU each engine's weight-stationary launches stay on
     CUs / nets workgroups per net (one round): the CUs they leave idle are where the other engine's kernels run (orl_config::ws_one_round)."""
     engines = []
     for e in range(E):
-        g = bw.make_engine("cql", R, precision, device, seed0 * E + e, ws_one_round=(E > 1) if one_round is None else one_round)
+        g = bw.make_engine("cql", R, precision, device, seed0 * E + e, ws_one_round=(E > 1) if one_round is None else one_round,
+                           obs_dim=od, act_dim=ad, target_entropy=-float(ad))
         g.attach_buffer(buf)                              # all engines of a GPU sample the same HBM-resident dataset
         engines.append(g)
     return engines
@@ -165,7 +173,7 @@ def timed_rate(engines, steps, min_seconds, min_reps=1, max_reps=40):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# CPU baselines (rank 0, N = 1): the torch-CPU counterpart at all cores and at 1 thread, and the numpy oracle
+# CPU baselines (rank 0, N = 1): the torch-CPU counterpart at up to 64 threads, 16 threads and 1 thread, and the numpy oracle
 # ---------------------------------------------------------------------------------------------------------------
 def _checker_paths():
     for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
@@ -188,7 +196,7 @@ def _cql_cpu_state():
 
 def cpu_baseline(seconds=24.0):
     """the build's PyTorch-CPU counterpart of CQLPolicy.learn (oracle/torch_cql.py, pinned against the
-    reference fixtures in tests/test_oracle_golden.py) on this box's host cores -- all cores available to the process and one
+    reference fixtures in tests/test_oracle_golden.py) on this box's host cores -- min(cores available, 64) threads, 16 threads and one
     thread -- plus the numpy oracle; same synthetic workload, a bounded sample of steps each."""
     _checker_paths()
     import synth
@@ -219,7 +227,7 @@ def cpu_baseline(seconds=24.0):
     per = seconds / 4
     out = {}
     old_threads = torch.get_num_threads()
-    for label, th in (("all", max(1, min(avail, 64))), ("t16", min(16, avail)), ("one", 1)):
+    for label, th in (("t64", max(1, min(avail, 64))), ("t16", min(16, avail)), ("one", 1)):      # (more than 64 threads only slow a batch-256 step down)
         torch.set_num_threads(th)
         st, rng = _cql_cpu_state()
         pol = TorchCQL(st, cfg)
@@ -236,12 +244,12 @@ def cpu_baseline(seconds=24.0):
     rate, n = time_it(lambda: ocql.learn(st, cfg, *sample(rng)), per)
     if ctx is not None and hasattr(ctx, "unregister"):
         ctx.unregister()
-    best = max(("all", "t16"), key=lambda k: out[k]["value"])
+    best = max(("t64", "t16"), key=lambda k: out[k]["value"])
     return dict(value=out[best]["value"], unit="gradient-steps/s", cores=out[best]["threads"], kind="port",
                 sample=f"{out[best]['steps']} CQL learn() steps (batch 256, ~{per:.0f} s) of the PyTorch-CPU counterpart (oracle/torch_cql.py: stock "
                        f"autograd + torch.optim.Adam) at {out[best]['threads']} torch threads; host reports {ncpu} cpus, {avail} available to the process",
                 nproc=ncpu, cpus_available=avail,
-                torch_all_cores=out["all"], torch_16_threads=out["t16"], torch_1_thread=out["one"],
+                torch_up_to_64_threads=out["t64"], torch_16_threads=out["t16"], torch_1_thread=out["one"],
                 numpy_oracle=dict(value=rate, blas_threads=min(16, avail), steps=n))
 
 
@@ -367,7 +375,8 @@ def api_record(device, precision, R, steps, dataset):
                     alpha=(-float(ACT), log_alpha, torch.optim.Adam([log_alpha], lr=1e-4)), cql_weight=5.0, temperature=1.0,
                     max_q_backup=False, deterministic_backup=True, with_lagrange=False, lagrange_threshold=10.0, cql_alpha_lr=3e-4,
                     num_repeart_actions=NREP)
-    pol.set_engine_options(n_runs=R, precision=precision, seed=5)
+    if precision is not None:
+        pol.set_engine_options(n_runs=R, precision=precision, seed=5)
     n = len(dataset["rew"])
     buf = ReplayBuffer(n, (OBS,), np.float32, ACT, np.float32, device=dev)
     buf.load_dataset(dict(observations=dataset["obs"], actions=dataset["act"], next_observations=dataset["nobs"],
@@ -389,7 +398,9 @@ def api_record(device, precision, R, steps, dataset):
     if pol.engine is not None:
         pol.engine.close()
     return dict(what="MFPolicyTrainer fused epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer (reference constructor signatures), "
-                     "%d steps per epoch, n_runs=%d, precision=%d, one engine, evaluation excluded" % (steps, R, precision),
+                     "%d steps per epoch, %s, one engine, evaluation excluded" % (
+                         steps, "n_runs=%d, precision=%d" % (R, precision) if precision is not None else
+                         "NO set_engine_options call: one policy in the product's default precision (exact fp32), what run_cql.py gets unchanged"),
                 value=R * steps / dt, unit="gradient-steps/s", epoch_seconds=times, finite=finite)
 
 
@@ -461,7 +472,7 @@ def main():
     ap.add_argument("--cpu-baseline-seconds", type=float, default=24.0, help="CPU work of the cpu_baseline sample (four legs share it)")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--profile-dump", default="", help="write the full per-launch-tag timing table (HIP events) to this file")
-    ap.add_argument("--dataset-size", type=int, default=1_000_000)
+    ap.add_argument("--dataset-size", type=int, default=None, help="transitions of the synthetic buffer (default 1 000 000; --preset config5: the rank's D4RL task size)")
     ap.add_argument("--launch-check", action="store_true", help="print this rank's RANK / LOCAL_RANK / WORLD_SIZE as JSON and exit (no GPU use)")
     ap.add_argument("--rccl-check", action="store_true", help="world-size-1 `nccl` process group on this GPU: the path's collectives on device tensors, then exit")
     args = ap.parse_args()
@@ -502,10 +513,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); torch.cuda.is_available() is False")
 
     from offlinerlkit import _engine
-    ds = make_dataset(rank, args.dataset_size)             # one task buffer per GPU (config 5: task = rank)
-    buf = _engine.DeviceBuffer(OBS, ACT, local_rank)
+    # one task buffer per GPU.  --preset config5: rank r trains D4RL-mujoco task r % 8 (its own observation / action widths and size)
+    task = CONFIG5_TASKS[rank % len(CONFIG5_TASKS)] if args.preset == "config5" else ("halfcheetah-medium-v2", OBS, ACT, 1_000_000)
+    od, ad = task[1], task[2]
+    if args.dataset_size is None:
+        args.dataset_size = task[3]
+    ds = make_dataset(rank, args.dataset_size, od, ad)
+    buf = _engine.DeviceBuffer(od, ad, local_rank)
     buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
-    engines = make_cql_engines(E, R, local_rank, args.precision, rank, buf)
+    engines = make_cql_engines(E, R, local_rank, args.precision, rank, buf, od=od, ad=ad)
     eng = engines[0]
 
     def barrier():
@@ -552,7 +568,7 @@ def main():
     dt_med = float(np.median(reps))
     value = total_steps / dt_med
     if rank == 0:
-        flops_step = cql_algorithmic_flops()
+        flops_step = cql_algorithmic_flops(od=od, ad=ad)
         roof = None
         if args.profile_steps > 0:
             roof = profile_roofline(eng, args.profile_steps, args.precision, R, flops_step, value / world, args.profile_dump)
@@ -566,9 +582,9 @@ def main():
         for g in engines:
             g.close()
         engines = []
-        sides = world == 1 and not args.no_sides
+        sides = world == 1 and not args.no_sides and (od, ad) == (OBS, ACT)
         by_runs, fp32, others = None, None, None
-        api = None
+        api, api_default, config5 = None, None, None
         if sides:
             by_runs = []                                 # (single side engines run alone on the GPU: whole rounds of workgroups)
             for r_side in (1, 8, 32, 96):
@@ -595,6 +611,26 @@ def main():
                     g.close()
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
+            # the drop-in number: CQLPolicy exactly as run_cql.py:80-128 builds it -- one policy, no set_engine_options (n_runs 1, the product's
+            # default precision = exact fp32) -- through the same fused MFPolicyTrainer epoch
+            api_default = api_record(local_rank, None, 1, 1000, ds)
+            # BASELINE configs[4] per GPU (what each rank of `--gpus 8 --preset config5` runs): one engine x 8 seeds on one task buffer, at
+            # both D4RL-mujoco shapes, measured one after the other on this GPU
+            config5 = []
+            for name, t_od, t_ad, t_n in (CONFIG5_TASKS[0], CONFIG5_TASKS[1]):
+                t_ds = ds if (t_od, t_ad) == (od, ad) else make_dataset(1, min(t_n, 400_000), t_od, t_ad)
+                t_buf = buf if t_ds is ds else _engine.DeviceBuffer(t_od, t_ad, local_rank)
+                if t_buf is not buf:
+                    t_buf.load(t_ds["obs"], t_ds["act"], t_ds["nobs"], t_ds["rew"], t_ds["term"])
+                es = make_cql_engines(1, 8, local_rank, args.precision, 300, t_buf, od=t_od, ad=t_ad)
+                learn_all(es, 30)
+                rr = timed_rate(es, 500, 0.6)
+                d = float(np.median(rr))
+                config5.append(dict(task=name, obs=t_od, act=t_ad, runs_per_gpu=8, engines_per_gpu=1, value=8 * 500 / d, ms_per_step=d / 500 * 1e3,
+                                    algorithmic_gflop_per_gradient_step=cql_algorithmic_flops(od=t_od, ad=t_ad) / 1e9))
+                es[0].close()
+                if t_buf is not buf:
+                    t_buf.close()
         cpu = cpu_baseline(args.cpu_baseline_seconds) if (world == 1 and not args.no_cpu_baseline) else None      # reported baseline: rank 0 at N = 1 only
         out = {
             "metric": "gradient-steps/sec (CQL, batch=256)", "value": value, "unit": "gradient-steps/s",
@@ -607,15 +643,21 @@ def main():
                        "value_fp32_over_target": ((value / world if args.precision == 0 else fp32["value"]) / TARGET_STEPS_PER_S) if (fp32 or args.precision == 0) else None,
                        "note": "BASELINE.json north_star target, per GPU; published reference numbers: none (vs_baseline null)"},
             "data": "synthetic D4RL-shaped replay buffer (N(0,1) obs, tanh actions), random-init weights",
-            "config": {"workload": "CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
-                                   "auto-alpha, device sampling+noise, %d engine(s) x %d run(s) per GPU x %d GPU(s) (independent seeds; value = steps of all runs)" % (E, R, world),
+            "config": {"workload": ("CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
+                                    "auto-alpha, device sampling+noise, %d engine(s) x %d run(s) per GPU x %d GPU(s) (independent seeds; value = steps of all runs)" % (E, R, world))
+                                   if args.preset != "config5" else
+                                   ("CQL, 8 seeds x 8 D4RL-mujoco tasks (BASELINE configs[4]): rank r trains task r %% 8 on its own synthetic buffer "
+                                    "(obs/act %s), batch 256, MLP [256,256], 10 repeat actions, auto-alpha, device sampling+noise, one engine x %d seeds per GPU x %d GPU(s)"
+                                    % (", ".join("%s %d/%d" % (CONFIG5_TASKS[r % len(CONFIG5_TASKS)][0], CONFIG5_TASKS[r % len(CONFIG5_TASKS)][1], CONFIG5_TASKS[r % len(CONFIG5_TASKS)][2]) for r in range(world)), R, world)),
                        "preset": args.preset, "runs_per_gpu": R * E, "engines_per_gpu": E, "runs_per_engine": R,
+                       "tasks_by_rank": [CONFIG5_TASKS[r % len(CONFIG5_TASKS)][0] for r in range(world)] if args.preset == "config5" else None,
                        "dataset_transitions": args.dataset_size, "task_buffers": world, "event_ms_per_step": ev_ms / args.steps,
                        "algorithmic_gflop_per_gradient_step": flops_step / 1e9, "rccl_world_size": world,
                        "dist_backend": backend if world > 1 else None},
             "reps": {"blocks": len(reps), "steps_per_block": args.steps, "block_seconds": reps, "value_is": "median block",
                      "value_min": total_steps / max(reps), "value_max": total_steps / min(reps), "seconds_timed": float(np.sum(reps))},
             "roofline": roof, "cpu_baseline": cpu, "fp32": fp32, "by_runs": by_runs, "other_configs": others, "api": api,
+            "api_default": api_default, "config5_per_gpu": config5,
             "single_run": by_runs[0] if by_runs else None,
             "metrics_gathered": {"shape": list(metrics_all.shape), "loss_critic1_mean_per_rank": [float(x) for x in metrics_all[:, :, 1].mean(axis=1)]},
             "final_metrics_rank0_run0": dict(zip(eng.metric_names, [float(x) for x in metrics[0]])),

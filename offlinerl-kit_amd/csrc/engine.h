@@ -121,7 +121,7 @@ struct Engine {
   int nm = 0;
   std::vector<std::string> metric_names;
   Buffer* buf = nullptr;       // attached replay buffer (not owned)
-  long long* d_idx = nullptr;  // [R][B] minibatch indices of the current step (k_draw_indices)
+  long long* d_idx = nullptr;  // [R][B] minibatch indices of the current step (recorded by k_prepare's rewards job)
   unsigned long long buf_gen = 0;   // Buffer::gen the captured graphs were built against
   void drop_graphs();
   // split-K slab table of the last adam() launch per net (orl_debug_grads sums the slabs the way k_adam does)

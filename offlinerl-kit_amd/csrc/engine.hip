@@ -1147,7 +1147,7 @@ int Engine::enqueue_prepare(bool sampling, bool devnoise) {
     p.d_obs = buf->obs; p.d_nobs = buf->nobs; p.d_act = buf->act; p.d_rew = buf->rew; p.d_term = buf->term; p.n = buf->n;
     p.OP = buf->OP; p.AP = buf->AP;
     // the minibatch indices (np.random.randint(0, size, B), buffer.py:98) are drawn inside k_prepare by every consumer of a batch row
-    // (same Philox counter -> same index) and recorded once in d_idx: no separate k_draw_indices node in front of the step
+    // (same Philox counter -> same index) and recorded once in d_idx: no separate index-drawing node in front of the step
     p.idx = d_idx; p.idx_rs = B; p.draw = 1; p.idx_out = d_idx;
   }
   Mat o2 = W("b_obs2");

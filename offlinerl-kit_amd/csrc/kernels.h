@@ -209,7 +209,7 @@ __global__ void k_dropout(float* h, long h_rs, long h_cs, int pitch, const float
 // matrices X = (obs | act | 0-pad) with repeated rows, and all noise arrays — instead of 1 gather + N noise +
 // M assemble launches.  A job table (<= 20 entries, passed by value) describes the outputs; one thread per
 // output element (four elements for the noise jobs: one Philox4x32 call each).  Observation-like sources are read either
-// straight from the HBM dataset through the step's minibatch indices (sampling mode: k_draw_indices runs first) or from the
+// straight from the HBM dataset through the step's minibatch indices (sampling mode: every consumer draws its row's index from the same Philox counter, orl_draw_index) or from the
 // batch slots (teacher-forced mode).
 // ------------------------------------------------------------------------------------------------
 enum { PS_OBS = 0, PS_NOBS = 1, PS_ACT = 2, PS_REW = 3, PS_TERM = 4, PS_NORMAL = 5, PS_UNIFORM = 6, PS_BUF = 7, PS_ZERO = 8 };
@@ -247,12 +247,6 @@ __device__ inline long long orl_draw_index(unsigned long long seed, int r, int b
   uint32_t o[4];
   ph((uint32_t)b, 0x51u, (uint32_t)ctr, 0x1D5u ^ (uint32_t)(ctr >> 32), o);
   return (long long)(((unsigned long long)o[0] * (unsigned long long)n) >> 32);
-}
-// (stand-alone form: orl_buffer_sample and engines without a k_prepare job table)
-__global__ void k_draw_indices(long long* out, long out_rs, int B, long n, unsigned long long seed, const unsigned long long* gstep) {
-  const int r = blockIdx.y, b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  out[(long)r * out_rs + b] = orl_draw_index(seed, r, b, *gstep, n);
 }
 __global__ void k_prepare(PrepP p) {
   const int r = blockIdx.y;

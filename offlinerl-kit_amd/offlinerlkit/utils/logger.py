@@ -6,6 +6,7 @@ the package is absent).  Not on the GPU path: MFPolicyTrainer calls it once per 
 """
 from __future__ import annotations
 
+import argparse
 import datetime
 import json
 import os
@@ -13,6 +14,7 @@ import sys
 from collections import defaultdict
 from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
 
+DEBUG, INFO, WARN, ERROR, BACKUP = 10, 20, 30, 40, 60      # level constants of the reference module (logger.py:16-20)
 DEFAULT_X_NAME = "timestep"
 ROOT_DIR = "logs"
 
@@ -126,6 +128,7 @@ class Logger:
         self._name2val: Dict[Any, Any] = defaultdict(float)
         self._name2cnt: Dict[Any, int] = defaultdict(int)
         self._timestep = 0
+        self._level = INFO
 
     def log_hyperparameters(self, hyper_param: Dict) -> None:
         with open(os.path.join(self._record_dir, "hyper_param.json"), "w") as f:
@@ -148,7 +151,8 @@ class Logger:
         self._name2val.clear()
         self._name2cnt.clear()
 
-    def log(self, s: str, level=None) -> None:
+    def log(self, s: str, level=INFO) -> None:
+        # (like the reference, `level` is accepted and stored by set_level but does not filter: logger.py:311-314, 322-323)
         for sink in self._sinks:
             if isinstance(sink, _TableSink):
                 sink.write_text(s)
@@ -158,6 +162,9 @@ class Logger:
         for s in self._sinks:
             if isinstance(s, _TbSink):
                 s.step = timestep
+
+    def set_level(self, level) -> None:
+        self._level = level
 
     record_dir = property(lambda self: self._record_dir)
     checkpoint_dir = property(lambda self: self._checkpoint_dir)
@@ -179,3 +186,10 @@ def make_log_dirs(task_name: str, algo_name: str, seed: Union[int, str], args: D
     path = os.path.join(*parts)
     os.makedirs(path)
     return path
+
+
+def load_args(load_path: str) -> argparse.Namespace:
+    """hyper_param.json (written by ``log_hyperparameters``) back as the Namespace a launch script's ``get_args()`` returns
+    (logger.py:367-371)."""
+    with open(load_path, "r") as f:
+        return argparse.Namespace(**json.load(f))

@@ -366,17 +366,21 @@ def gen_edac(ref, case):
     return out
 
 
-GENERATORS = {"cql": (gen_cql, list(synth.CQL_CASES)), "iql": (gen_iql, list(synth.IQL_CASES)),
+GENERATORS = {"cql": (gen_cql, list(synth.CQL_CASES) + list(synth.CQL_EXTRA_CASES)), "iql": (gen_iql, list(synth.IQL_CASES)),
               "td3bc": (gen_td3bc, list(synth.TD3BC_CASES)), "edac": (gen_edac, list(synth.EDAC_CASES))}
 
 
 def main(argv):
+    # arguments: algorithm names, or algo:case to regenerate one fixture (e.g. cql:cql_hopper)
     algos = argv[1:] or list(GENERATORS)
     ref = _import_reference()
     torch.set_num_threads(4)
-    for algo in algos:
+    for arg in algos:
+        algo, _, only = arg.partition(":")
         fn, cases = GENERATORS[algo]
         for case in cases:
+            if only and case != only:
+                continue
             out = fn(ref, case)
             path = os.path.join(HERE, f"{case}.npz")
             np.savez_compressed(path, **out)

@@ -165,10 +165,13 @@ CQL_CASES = {
     "cql_tiny_h3": dict(obs_dim=4, act_dim=2, hidden=[32, 32, 32], B=8, N=4, steps=3, seed=105, over={}),
     "cql_halfcheetah": dict(obs_dim=17, act_dim=6, hidden=[256, 256], B=256, N=10, steps=20, seed=7, over={}),
     "cql_halfcheetah_h3": dict(obs_dim=17, act_dim=6, hidden=[256, 256, 256], B=256, N=10, steps=3, seed=8, over={}),
+    # BASELINE configs[4] names 8 D4RL-mujoco tasks: the hopper shape (critic input 11 + 3 = 14 columns, actor head 6 outputs)
+    "cql_hopper": dict(obs_dim=11, act_dim=3, hidden=[256, 256], B=256, N=10, steps=8, seed=11, over={}),
 }
 
 
-# Shapes that are checked against the oracle only (no reference fixture): they exercise kernel-selection corners of the HIP engine
+# Shapes that exercise kernel-selection corners of the HIP engine at full size (reference fixtures since round 4: make_golden.py
+# generates them like CQL_CASES; three steps each, losses + Q taps + parameter digests)
 CQL_EXTRA_CASES = {
     # 111-dimensional observations (Ant-like): the first layer is too wide to be fused into the weight-stationary forward
     "cql_wide_obs": dict(obs_dim=111, act_dim=8, hidden=[256, 256], B=256, N=10, steps=3, seed=301, over={}),

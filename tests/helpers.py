@@ -32,6 +32,23 @@ def rel_err(a, b, floor=1e-3):
     return float((np.abs(a - b) / np.maximum(np.abs(b), floor * scale)).max())
 
 
+def key_scales(g):
+    """Per-key scale of a fixture's loss table: max |value| of that key over the teacher-forced window."""
+    n = 0
+    while f"step{n}/losses" in g.files:
+        n += 1
+    return np.abs(np.stack([g[f"step{k}/losses"] for k in range(n)])).max(axis=0)
+
+
+def rel_err_keys(a, b, scales, floor=1e-2):
+    """max_i |a_i - b_i| / max(|b_i|, floor * scales_i): every metric is held to a RELATIVE bound of its own; the absolute floor (for a
+    loss that crosses zero inside the window, e.g. loss/alpha) is tied to that key's own scale over the fixture, not to the largest key
+    of the step (rel_err's floor lets a metric 100x smaller than loss/critic through at an absolute 1e-6 of loss/critic)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float((np.abs(a - b) / np.maximum(np.abs(b), floor * np.maximum(np.asarray(scales, np.float64), 1e-30))).max())
+
+
 def scale_err(a, b):
     """max |a-b| / max |b|: error relative to the tensor's scale (the 1e-4 gate for Q-value arrays)."""
     a = np.asarray(a, np.float64).ravel()

@@ -6,10 +6,10 @@ import numpy as np
 import pytest
 
 import synth
-from helpers import load_golden, cql_oracle_setup, rel_err, scale_err, check_state_against_golden
+from helpers import load_golden, cql_oracle_setup, rel_err, rel_err_keys, key_scales, scale_err, check_state_against_golden
 
 
-@pytest.mark.parametrize("case", list(synth.CQL_CASES))
+@pytest.mark.parametrize("case", list(synth.CQL_CASES) + list(synth.CQL_EXTRA_CASES))
 def test_cql_oracle_matches_reference(case):
     from oracle import cql as ocql
     g = load_golden(case)
@@ -21,6 +21,7 @@ def test_cql_oracle_matches_reference(case):
         got = np.array([res[x] for x in keys])
         ref = g[f"step{k}/losses"]
         assert rel_err(got, ref, floor=1e-2) < 1e-4, (case, k, got, ref)
+        assert rel_err_keys(got, ref, key_scales(g)) < 1e-4, (case, k, got, ref)      # every key against its OWN scale over the window
         if k == 0:
             assert scale_err(aux["q1a"], g["step0/c1_qa"]) < 1e-5
             assert scale_err(aux["q2a"], g["step0/c2_qa"]) < 1e-5

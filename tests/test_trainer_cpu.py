@@ -77,6 +77,23 @@ def test_logger_csv_grows_header_and_means(tmp_path):
         os.chdir(cwd)
 
 
+def test_logger_hyperparameters_round_trip_and_level(tmp_path):
+    """log_hyperparameters -> hyper_param.json -> load_args gives back the Namespace a launch script's get_args() returned
+    (logger.py:264-270, 367-371); set_level stores the level and, as in the reference (logger.py:311-323), does not filter log()."""
+    from offlinerlkit.utils import logger as L
+    lg = L.Logger(str(tmp_path), {"consoleout_backup": "stdout"})
+    args = dict(algo_name="cql", task="hopper-medium-v2", seed=3, hidden_dims=[256, 256], actor_lr=1e-4, auto_alpha=True, device="cuda:0")
+    lg.log_hyperparameters(args)
+    ns = L.load_args(os.path.join(lg.record_dir, "hyper_param.json"))
+    assert vars(ns) == args
+    assert lg._level == L.INFO
+    lg.set_level(L.DEBUG)
+    assert lg._level == L.DEBUG == 10
+    lg.log("still written", level=L.DEBUG)
+    lg.close()
+    assert "still written" in open(tmp_path / "record" / "consoleout_backup.txt").read()
+
+
 WORKER = r'''
 import os, sys, json
 import numpy as np
