@@ -26,7 +26,12 @@
  *     into the fp32 accumulators), 3 MFMAs per product, fp32 accumulate;
  *     orl_split_bits() reports the operand width of the loaded build (22; 16
  *     for the bf16-plane variant build).  In this mode hidden activations
- *     and inputs must stay below 65504 in magnitude (fp16 range).
+ *     and inputs must stay below 65504 in magnitude (fp16 range) and weights
+ *     below 1023 (they enter the products times 2^6): see orl_health.
+ *   - orl_step / orl_learn_n additionally return ORL_RC_UNHEALTHY (1) when the
+ *     step(s) ran but a run's health flag is raised (non-finite loss or
+ *     gradient, an operand beyond the split-precision range): results are
+ *     delivered, orl_last_error() describes the runs, orl_health() has the flags.
  */
 #ifndef ORL_ENGINE_H
 #define ORL_ENGINE_H
@@ -43,6 +48,14 @@ extern "C" {
 #define ORL_ALGO_EDAC 3  /* policy/model_free/edac.py:88-166  */
 #define ORL_ALGO_SAC 4   /* policy/model_free/sac.py:88-140 (MOPOPolicy.learn on the real+model batch, model_based/mopo.py:81-84) */
 #define ORL_ALGO_MCQ 5   /* policy/model_free/mcq.py:48-126 (SAC critics / actor + the VAE behaviour policy of nets/vae.py) */
+
+/* per-run health flags (orl_health).  The reference raises nothing when a run diverges (its losses simply turn nan); here a diverging run
+ * can additionally be MASKED by the arithmetic -- the ReLU of the matrix kernels works on the integer view of the activations and maps a NaN
+ * whose sign bit is set to +0, and at precision 1 an operand beyond the fp16-plane range multiplies to NaN -- so the engine watches for it. */
+#define ORL_HEALTH_NONFINITE_LOSS 1 /* a metric of a step (loss, alpha, Q statistic) was inf / nan */
+#define ORL_HEALTH_NONFINITE_GRAD 2 /* a summed parameter gradient was inf / nan when Adam consumed it */
+#define ORL_HEALTH_SPLIT_RANGE 4    /* precision 1: an input, stored hidden activation (|x| >= 65504) or weight (|w| >= 65504 / 2^6) is out of the operand range */
+#define ORL_RC_UNHEALTHY 1
 
 #define ORL_MAX_HIDDEN 4
 #define ORL_MAX_METRICS 8
@@ -219,6 +232,15 @@ int orl_step(orl_engine* e, const orl_batch* batch, const orl_noise* noise, floa
  * sampling and noise on device; metrics_mean: host [n_runs][ORL_MAX_METRICS] epoch means;
  * elapsed_ms (optional): HIP-event time of the n steps on the engine stream. */
 int orl_learn_n(orl_engine* e, int n_steps, float* metrics_mean, float* elapsed_ms);
+/* Sticky per-run health flags (ORL_HEALTH_* bits), flags_out: host uint32[n_runs] (may be NULL); returns the OR over the runs, < 0 on
+ * error.  orl_step / orl_learn_n update the flags from what they already read back (metrics; one word per run that k_adam raises on a
+ * non-finite gradient) and, at precision 1, scan the step's MFMA operands for the fp16-plane range when a run turned non-finite.
+ * orl_health_check runs that range scan on demand (inputs, stored hidden activations and parameters of the LAST step; a pass over
+ * the workspaces, not for the inner loop: MFPolicyTrainer calls it once per epoch); orl_health_clear resets the flags (after
+ * load_state_dict / a restart of the diverged runs). */
+int orl_health(orl_engine* e, uint32_t* flags_out);
+int orl_health_check(orl_engine* e, uint32_t* flags_out);
+int orl_health_clear(orl_engine* e);
 int orl_num_metrics(orl_engine* e);
 const char* orl_metric_name(orl_engine* e, int idx);
 int64_t orl_step_count(orl_engine* e);

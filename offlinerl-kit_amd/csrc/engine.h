@@ -91,6 +91,7 @@ struct Buffer {             // HBM-resident replay buffer (buffer/buffer.py)
   float *obs = nullptr, *nobs = nullptr, *act = nullptr, *rew = nullptr, *term = nullptr;
   long long* idx = nullptr; long idx_cap = 0;
   unsigned long long counter = 0;
+  float absmax = -1.f; unsigned long long absmax_gen = ~0ull;   // max |obs|, |next_obs|, |act| of generation absmax_gen (engines at precision 1 ask for it)
   unsigned long long gen = 0;   // bumped by every orl_buffer_load: engines re-capture graphs that hold the old dataset pointers / size
   ~Buffer();
 };
@@ -173,6 +174,18 @@ struct Engine {
   float* gscale_slot();              // next slot for a seed kernel that publishes the scale itself (GradScaleP-free path); null at precision 0
   float* gscale_inv_b = nullptr;     // [R] constant scale of seeds whose entries are +-1/B (actor-loss dq)
   unsigned int* cql_ticket = nullptr;  // [R] arrival counters of k_cql_loss_rows
+  // health (include/orl_engine.h: ORL_HEALTH_*): device words raised by kernels (k_adam: non-finite gradient; k_range_scan), the sticky
+  // host copy that also holds what the host finds in the metrics it reads back, and the matrices of the last enqueued step that enter
+  // the MFMAs as fp16 planes with operand scale 1 (registered by linear_fwd / mlp_forward while the step is enqueued or captured)
+  unsigned int* health = nullptr;      // [R]
+  std::vector<unsigned int> health_host;
+  struct RangeWatch { Mat m; int rows, cols, nets; std::string what; };
+  std::map<const float*, RangeWatch> range_watch;
+  void watch_range(const Mat& m, int rows, int cols, int nets, const char* what);
+  int range_scan();                    // enqueues k_range_scan for every watched matrix and the parameters (precision 1)
+  int health_update(const float* metrics, long steps_done, unsigned int* any);   // after a stream sync; metrics: [R][nm] values just read back (or null)
+  long steps_since_scan = 0;           // precision 1: the operands of the last step are range-scanned every RANGE_SCAN_EVERY steps (and when a run turns non-finite)
+  enum { RANGE_SCAN_EVERY = 256 };
 
   ~Engine();
   int init(const orl_config& c);

@@ -298,6 +298,74 @@ const float* Engine::grad_scale(const Mat& seed, int rows, int cols, int nets, c
   return out;
 }
 
+void Engine::watch_range(const Mat& m, int rows, int cols, int nets, const char* what) {
+  if (cfg.precision != 1 || !m.p) return;
+  RangeWatch w{m, rows, cols, nets, what ? what : ""};
+  range_watch[m.p] = w;
+}
+
+// every matrix the last enqueued step feeds to the split-precision MFMAs at operand scale 1 (dead ones -- never stored by the forward pass --
+// skipped), then the parameters of every net (operand scale ORL_WSCALE)
+int Engine::range_scan() {
+  if (cfg.precision != 1) return 0;
+  const float lim = 65504.0f;
+  for (auto& kv : range_watch) {
+    const RangeWatch& w = kv.second;
+    if (vals_dead.count(w.m.p)) continue;
+    hipLaunchKernelGGL(k_range_scan, dim3(R), dim3(256), 0, stream, (const float*)w.m.p, w.m.rs, w.m.cs, w.nets, w.rows, w.cols, w.m.pitch, lim, health);
+  }
+  hipLaunchKernelGGL(k_range_scan, dim3(R), dim3(256), 0, stream, (const float*)arena, P_train, 0L, 1, 1, (int)P_train, (int)P_train, lim / ORL_WSCALE, health);
+  if (P_tgt > 0)
+    hipLaunchKernelGGL(k_range_scan, dim3(R), dim3(256), 0, stream, (const float*)(arena + (long)R * P_train), P_tgt, 0L, 1, 1, (int)P_tgt, (int)P_tgt, lim / ORL_WSCALE, health);
+  return hipGetLastError() == hipSuccess ? 0 : fail("range scan launch");
+}
+
+// Called after the stream has been synchronised: folds what the host just read (non-finite metrics) and what the kernels raised into the
+// sticky per-run flags.  A split-precision engine gets the operands of its last step scanned for the fp16-plane range when a run turned
+// non-finite (so the report can name the cause) and every RANGE_SCAN_EVERY steps: an activation beyond 65504 does NOT surface by itself --
+// its hi / lo planes are +inf / -inf, the MFMA adds them to the NaN 0xffc00000 (tools/probes/nan_sign_probe.hip, measured on gfx950), and
+// a ReLU (integer view or v_max_f32 alike) turns a sign-bit NaN into +0: the row's next layer is silently all zero.  The scan is a pass
+// over the workspaces (~0.1 % of 256 steps); steps_done < 0: scan now (orl_health_check).
+// *any = OR over the runs.  Sets the error string (not the return code) when a flag is up.
+int Engine::health_update(const float* metrics, long steps_done, unsigned int* any) {
+  std::vector<unsigned int> dv(R);
+  ORL_HIP(hipMemcpy(dv.data(), health, sizeof(unsigned int) * R, hipMemcpyDeviceToHost));
+  bool fresh = false;
+  for (int r = 0; r < R; ++r) {
+    unsigned int f = dv[r];
+    if (metrics)
+      for (int k = 0; k < nm; ++k) if (!std::isfinite(metrics[(long)r * nm + k])) f |= ORL_HEALTH_NONFINITE_LOSS;
+    if (f & ~health_host[r]) fresh = true;
+    health_host[r] |= f;
+  }
+  steps_since_scan += steps_done > 0 ? steps_done : 0;
+  if (cfg.precision == 1 && (fresh || steps_done < 0 || steps_since_scan >= RANGE_SCAN_EVERY)) {
+    steps_since_scan = 0;
+    if (range_scan()) return -1;
+    ORL_HIP(hipStreamSynchronize(stream));
+    ORL_HIP(hipMemcpy(dv.data(), health, sizeof(unsigned int) * R, hipMemcpyDeviceToHost));
+    for (int r = 0; r < R; ++r) health_host[r] |= dv[r];
+  }
+  unsigned int all = 0;
+  for (int r = 0; r < R; ++r) all |= health_host[r];
+  if (any) *any = all;
+  if (all) {
+    std::string msg = "unhealthy run(s):";
+    int listed = 0;
+    for (int r = 0; r < R && listed < 8; ++r) {
+      if (!health_host[r]) continue;
+      msg += " run " + std::to_string(r) + " [";
+      if (health_host[r] & ORL_HEALTH_NONFINITE_LOSS) msg += " non-finite loss";
+      if (health_host[r] & ORL_HEALTH_NONFINITE_GRAD) msg += " non-finite gradient";
+      if (health_host[r] & ORL_HEALTH_SPLIT_RANGE) msg += " operand beyond the split-precision range (|x| >= 65504 or |w| >= 1023.5: use precision 0 or normalise the inputs)";
+      msg += " ]";
+      ++listed;
+    }
+    set_error(msg);
+  }
+  return 0;
+}
+
 #define ORL_LAUNCH(tag, kernel, grid, block, ...)                                      \
   do {                                                                                 \
     prof_begin(tag, 0);                                                                \
@@ -338,6 +406,10 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
+  if (!x_dscale) {                                    // an input / activation operand (scale 1): orl_health_check scans it for the fp16-plane range
+    watch_range(X, M, in_rows, X.cs ? nr.nz1 : 1, tag);
+    if (fuse_X0) watch_range(*fuse_X0, M, l.layer_in(0), fuse_X0->cs ? nr.nz1 : 1, tag0 ? tag0 : tag);
+  }
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.b_scale = ORL_WSCALE; p.a_dscale = x_dscale;      // split precision: static scale of the weight operand, dynamic one of a gradient-like input
@@ -765,7 +837,7 @@ int Engine::adam(int net, int nnets, int lr_slot, const std::vector<std::pair<lo
   if (target_net >= 0) { a.target = net_ptr(0, target_net); a.t_s0 = P_tgt; a.t_s1 = l.stride(); }
   a.P = l.size; a.lr_slot = lr_slot; a.hy = hyper;
   a.b1 = cfg.adam_beta1; a.b2 = cfg.adam_beta2; a.eps = cfg.adam_eps; a.tau = cfg.tau;
-  a.gstep = gstep; a.t_div = t_div;
+  a.gstep = gstep; a.t_div = t_div; a.health = health;
   // algorithmic bytes: every gradient slab read once, m / v / parameter read and written, the Polyak target read and written
   double bytes = 0.0;
   for (int i = 0; i < a.nseg; ++i) bytes += (double)(a.seg_end[i] - (i ? a.seg_end[i - 1] : 0)) * (4.0 * a.seg_nslab[i] + 24.0 + (a.target ? 8.0 : 0.0));
@@ -821,6 +893,8 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
     if (small_fwd_supported(w)) {
       const int nz = R * nr.nz1;
+      watch_range(X, M, w.in0, X.cs ? nr.nz1 : 1, tag);
+      if (!fwd_only) watch_range(hs[0], M, SF_N, nr.nz1, tag);      // (h1 meets the tail weights in fp32 vector arithmetic)
       prof_begin(tag, 2.0 * M * (double)nz * (SF_N * (double)(w.in0 + 1) + (double)SF_N * SF_N + (double)SF_N * l.out_dim),
                  4.0 * nz * (M * (double)(X.pitch + (fwd_only ? 0 : 2 * SF_N) + l.out_dim) + (double)SF_N * (w.in0 + SF_N + l.out_dim + 2)));
       hipError_t err = launch_small_fwd(w, nz, stream);
@@ -1024,7 +1098,9 @@ int Engine::init(const orl_config& c) {
   gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
   gscale_inv_b = raw_alloc(sizeof(float) * (size_t)R);
   cql_ticket = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
-  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket) return fail("hipMalloc state");
+  health = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
+  health_host.assign(R, 0u);
+  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health) return fail("hipMalloc state");
   {
     std::vector<float> inv(R, orl_pow2_scale(1.0f / (float)c.batch_size));
     ORL_HIP(hipMemcpyAsync(gscale_inv_b, inv.data(), sizeof(float) * R, hipMemcpyHostToDevice, stream));
@@ -1423,6 +1499,7 @@ int orl_buffer_normalize_obs(orl_buffer* h, float eps, float* mean_out, float* s
                      (const float*)dm, (const float*)ds);
   ORL_HIP(hipDeviceSynchronize());
   hipFree(dm); hipFree(ds);
+  b.absmax_gen = ~0ull;                    // the values changed in place (same arrays: captured graphs stay valid, the cached range does not)
   if (mean_out) memcpy(mean_out, mean.data(), sizeof(float) * b.od);
   if (std_out) memcpy(std_out, sd.data(), sizeof(float) * b.od);
   return 0;
@@ -1459,6 +1536,31 @@ int orl_engine_attach_buffer(orl_engine* h, orl_buffer* b) {
   if (!b) { h->e.buf = nullptr; h->e.drop_graphs(); return 0; }
   if (b->b.od != h->e.od || b->b.ad != h->e.ad) return fail("attach_buffer: obs/act dims differ from the engine's");
   if (b->b.dev != h->e.dev) return fail("attach_buffer: buffer lives on another device");
+  if (h->e.cfg.precision == 1 && b->b.obs) {
+    // split precision multiplies fp16 hi + lo planes: an observation or action component of 65504 or more is +-inf there.  The dataset is
+    // checked once per load (a 40 us reduction over the HBM arrays), not per sampled batch.
+    Buffer& bb = b->b;
+    if (bb.absmax_gen != bb.gen) {
+      ORL_HIP(hipSetDevice(bb.dev));
+      unsigned int* d = nullptr;
+      ORL_HIP(hipMalloc((void**)&d, sizeof(unsigned int)));
+      ORL_HIP(hipMemset(d, 0, sizeof(unsigned int)));
+      hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, 0, (const float*)bb.obs, bb.n * bb.OP, d);
+      hipLaunchKernelGGL(k_absmax, dim3(1024), dim3(256), 0, 0, (const float*)bb.nobs, bb.n * bb.OP, d);
+      hipLaunchKernelGGL(k_absmax, dim3(512), dim3(256), 0, 0, (const float*)bb.act, bb.n * bb.AP, d);
+      unsigned int bits = 0;
+      ORL_HIP(hipMemcpy(&bits, d, sizeof(bits), hipMemcpyDeviceToHost));
+      hipFree(d);
+      memcpy(&bb.absmax, &bits, sizeof(float));
+      bb.absmax_gen = bb.gen;
+    }
+    if (!(bb.absmax < 65504.0f)) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "attach_buffer: the dataset's observations / actions reach |x| = %g, beyond the operand range of precision 1 "
+               "(fp16 hi + lo planes, |x| < 65504): normalise the observations (ReplayBuffer.normalize_obs) or use precision 0", (double)bb.absmax);
+      return fail(msg);
+    }
+  }
   h->e.buf = &b->b;
   h->e.buf_gen = b->b.gen;
   h->e.drop_graphs();             // captured graphs hold the old dataset pointers
@@ -1497,13 +1599,15 @@ int orl_step(orl_engine* h, const orl_batch* b, const orl_noise* nz, float* metr
   if (e.enqueue_step(e.step_variant())) return -1;
   e.step_host++;
   ORL_HIP(hipStreamSynchronize(e.stream));
+  std::vector<float> m(e.R * e.nm);
+  ORL_HIP(hipMemcpy(m.data(), e.metrics_last, sizeof(float) * m.size(), hipMemcpyDeviceToHost));
   if (metrics) {
-    std::vector<float> m(e.R * e.nm);
-    ORL_HIP(hipMemcpy(m.data(), e.metrics_last, sizeof(float) * m.size(), hipMemcpyDeviceToHost));
     for (int r = 0; r < e.R; ++r)
       for (int k = 0; k < ORL_MAX_METRICS; ++k) metrics[r * ORL_MAX_METRICS + k] = k < e.nm ? m[r * e.nm + k] : 0.f;
   }
-  return 0;
+  unsigned int bad = 0;
+  if (e.health_update(m.data(), 1, &bad)) return -1;
+  return bad ? ORL_RC_UNHEALTHY : 0;
 }
 
 int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_ms) {
@@ -1554,12 +1658,38 @@ int orl_learn_n(orl_engine* h, int n_steps, float* metrics_mean, float* elapsed_
   float ms = 0.f;
   ORL_HIP(hipEventElapsedTime(&ms, t0, t1));
   if (elapsed_ms) *elapsed_ms = ms;
+  std::vector<float> m(e.R * e.nm);
+  ORL_HIP(hipMemcpy(m.data(), e.metrics_sum, sizeof(float) * m.size(), hipMemcpyDeviceToHost));      // (a non-finite metric of ANY of the n steps stays in its sum)
   if (metrics_mean) {
-    std::vector<float> m(e.R * e.nm);
-    ORL_HIP(hipMemcpy(m.data(), e.metrics_sum, sizeof(float) * m.size(), hipMemcpyDeviceToHost));
     for (int r = 0; r < e.R; ++r)
       for (int k = 0; k < ORL_MAX_METRICS; ++k) metrics_mean[r * ORL_MAX_METRICS + k] = k < e.nm ? m[r * e.nm + k] / n_steps : 0.f;
   }
+  unsigned int bad = 0;
+  if (e.health_update(m.data(), n_steps, &bad)) return -1;
+  return bad ? ORL_RC_UNHEALTHY : 0;
+}
+
+int orl_health(orl_engine* h, uint32_t* flags_out) {
+  Engine& e = h->e;
+  unsigned int all = 0;
+  for (int r = 0; r < e.R; ++r) { all |= e.health_host[r]; if (flags_out) flags_out[r] = e.health_host[r]; }
+  return (int)all;
+}
+int orl_health_check(orl_engine* h, uint32_t* flags_out) {
+  Engine& e = h->e;
+  if (hipSetDevice(e.dev) != hipSuccess) { fail("hipSetDevice"); return -1; }
+  if (hipStreamSynchronize(e.stream) != hipSuccess) { fail("sync"); return -1; }
+  unsigned int all = 0;
+  if (e.health_update(nullptr, -1, &all)) return -1;
+  if (flags_out) for (int r = 0; r < e.R; ++r) flags_out[r] = e.health_host[r];
+  return (int)all;
+}
+int orl_health_clear(orl_engine* h) {
+  Engine& e = h->e;
+  ORL_HIP(hipSetDevice(e.dev));
+  ORL_HIP(hipMemsetAsync(e.health, 0, sizeof(unsigned int) * e.R, e.stream));
+  ORL_HIP(hipStreamSynchronize(e.stream));
+  e.health_host.assign(e.R, 0u);
   return 0;
 }
 

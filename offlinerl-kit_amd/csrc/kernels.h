@@ -7,6 +7,12 @@
 
 namespace orl {
 
+#ifndef ORL_HEALTH_NONFINITE_LOSS      // (include/orl_engine.h defines the same values for the C ABI)
+#define ORL_HEALTH_NONFINITE_LOSS 1
+#define ORL_HEALTH_NONFINITE_GRAD 2
+#define ORL_HEALTH_SPLIT_RANGE 4
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (device sampling of indices / noise in orl_learn_n)
 // ------------------------------------------------------------------------------------------------
@@ -673,6 +679,7 @@ struct AdamP {
   int lr_slot; const Hyper* hy;
   float b1, b2, eps, tau;
   const unsigned long long* gstep; unsigned long long t_div;  // t = gstep / t_div + 1
+  unsigned int* health;               // [z0] sticky per-run flags (ORL_HEALTH_*): a non-finite summed gradient sets ORL_HEALTH_NONFINITE_GRAD
 };
 // b^t for an integer step count by repeated squaring (a handful of double multiplies; the library pow() on one lane of every
 // workgroup was a measurable part of the launch)
@@ -742,6 +749,10 @@ __global__ void k_adam(AdamP p) {
       }
       gs = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
     }
+    // a diverging run shows here even when the forward pass scrubbed its NaNs (the integer-view ReLU maps sign-bit NaNs to +0, gemm.h):
+    // one compare per gradient in a kernel that waits for HBM
+    if (!(fabsf(gs[0]) <= 3.4e38f) || !(fabsf(gs[1]) <= 3.4e38f) || !(fabsf(gs[2]) <= 3.4e38f) || !(fabsf(gs[3]) <= 3.4e38f))
+      atomicOr(p.health + z0, (unsigned int)ORL_HEALTH_NONFINITE_GRAD);
     f4 m = *(const f4*)&p.m[o + i0], v = *(const f4*)&p.v[o + i0], w = *(const f4*)&p.params[o + i0];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -762,6 +773,7 @@ __global__ void k_adam(AdamP p) {
     int nslab = p.seg_nslab[0];
     for (int k = 1; k < p.nseg; ++k) if (i >= p.seg_end[k - 1]) nslab = p.seg_nslab[k];
     const float gs = adam_slab_sum(g + i, p.g_ks, nslab);
+    if (!(fabsf(gs) <= 3.4e38f)) atomicOr(p.health + z0, (unsigned int)ORL_HEALTH_NONFINITE_GRAD);
     float m = p.m[o + i], v = p.v[o + i], w = p.params[o + i];
     m = m + (gs - m) * (1.0f - p.b1);
     v = v * p.b2 + (1.0f - p.b2) * gs * gs;
@@ -769,6 +781,31 @@ __global__ void k_adam(AdamP p) {
     p.m[o + i] = m; p.v[o + i] = v; p.params[o + i] = w;
     if (tg) tg[i] = tg[i] * (1.0f - p.tau) + w * p.tau;
   }
+}
+
+// Range scan (orl_health_check; run by orl_step / orl_learn_n themselves when a split-precision run turns non-finite): one workgroup per
+// run walks a matrix that enters the MFMAs as fp16 hi + lo planes -- an input, a stored hidden activation (x 1) or the parameters
+// (x 2^6) -- and raises ORL_HEALTH_SPLIT_RANGE when an entry reaches `limit` (65504 over the operand scale): beyond it the hi plane is +-inf,
+// the lo plane -+inf, and every product that touches the element is NaN.  Not on the step's path.
+__global__ void k_range_scan(const float* x, long rs, long cs, int nets, int rows, int cols, int pitch, float limit, unsigned int* health) {
+  const int r = blockIdx.x;
+  const long per_net = (long)rows * cols, n = per_net * nets;
+  bool hit = false;
+  for (long e = threadIdx.x; e < n; e += blockDim.x) {
+    const long z = e / per_net, w = e - z * per_net;
+    const long row = w / cols, c = w - row * cols;
+    hit |= fabsf(x[(long)r * rs + z * cs + row * pitch + c]) >= limit;      // (NaN compares false: a diverged run is reported as non-finite, not as out of range)
+  }
+  if (__syncthreads_or(hit) && threadIdx.x == 0) atomicOr(health + r, (unsigned int)ORL_HEALTH_SPLIT_RANGE);
+}
+// max |x| of a dataset array (orl_engine_attach_buffer at precision 1: observations / actions beyond the split range are refused up front)
+__global__ void k_absmax(const float* x, long n, unsigned int* out_bits) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float a = fabsf(x[i]);
+    m = (a > m || a != a) ? a : m;                                            // a NaN sticks
+  }
+  atomicMax(out_bits, __float_as_uint(m));                                    // non-negative floats (and NaNs above them) order like their bit patterns
 }
 
 // q[m] += part[0][m] + part[1][m] + ... (column-tile partial sums of a tail fused into the last hidden layer's epilogue)

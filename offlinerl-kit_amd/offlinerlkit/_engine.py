@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -25,6 +26,18 @@ SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA_M, SCALAR_CQL_LOG_A
 ALL_SCALARS = (SCALAR_LOG_ALPHA, SCALAR_LOG_ALPHA_M, SCALAR_LOG_ALPHA_V, SCALAR_CQL_LOG_ALPHA, SCALAR_CQL_LOG_ALPHA_M,
                SCALAR_CQL_LOG_ALPHA_V, SCALAR_LAST_ACTOR_LOSS, SCALAR_ALPHA)      # set order: ALPHA last (LOG_ALPHA derives it)
 OPT_ACTOR, OPT_CRITIC, OPT_ALPHA, OPT_CQL_ALPHA, OPT_CRITIC_V, OPT_VAE = range(6)
+# per-run health flags (include/orl_engine.h) and the return code of a step that ran but left one raised
+HEALTH_NONFINITE_LOSS, HEALTH_NONFINITE_GRAD, HEALTH_SPLIT_RANGE = 1, 2, 4
+RC_UNHEALTHY = 1
+
+
+class EngineHealthWarning(RuntimeWarning):
+    """A run of the engine turned non-finite or left the operand range of split precision (``Engine.health()``)."""
+
+
+class EngineHealthError(RuntimeError):
+    """The same, raised instead of warned when ``Engine.strict_health`` (or ORL_STRICT_HEALTH=1) is set."""
+
 
 # symbols include/orl_engine.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -32,7 +45,8 @@ ABI_SYMBOLS = [
     "orl_engine_destroy", "orl_engine_sync", "orl_net_present", "orl_net_floats", "orl_net_num_tensors",
     "orl_net_tensor", "orl_net_ptr", "orl_net_set", "orl_net_get", "orl_scalar_set", "orl_scalar_get",
     "orl_set_lr", "orl_reset_optimizers", "orl_adam_get", "orl_adam_set", "orl_set_step_count", "orl_buffer_create", "orl_buffer_destroy", "orl_buffer_load",
-    "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n", "orl_num_metrics", "orl_metric_name", "orl_step_count",
+    "orl_buffer_normalize_obs", "orl_buffer_sample", "orl_buffer_size", "orl_engine_attach_buffer", "orl_step", "orl_learn_n",
+    "orl_health", "orl_health_check", "orl_health_clear", "orl_num_metrics", "orl_metric_name", "orl_step_count",
     "orl_debug_read", "orl_debug_read_bits", "orl_debug_grads", "orl_debug_gemm", "orl_debug_gemm_time", "orl_profile_enable", "orl_profile_query",
 ]
 
@@ -129,6 +143,9 @@ def load_library(path: Optional[str] = None):
     lib.orl_engine_attach_buffer.argtypes = [C.c_void_p, C.c_void_p]
     lib.orl_step.argtypes = [C.c_void_p, C.POINTER(OrlBatch), C.POINTER(OrlNoise), C.c_void_p]
     lib.orl_learn_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float)]
+    lib.orl_health.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orl_health_check.argtypes = [C.c_void_p, C.c_void_p]
+    lib.orl_health_clear.argtypes = [C.c_void_p]
     lib.orl_num_metrics.argtypes = [C.c_void_p]
     lib.orl_metric_name.argtypes = [C.c_void_p, C.c_int]
     lib.orl_metric_name.restype = C.c_char_p
@@ -198,6 +215,9 @@ class Engine:
         _check(self.lib.orl_engine_create(C.byref(cfg), C.byref(self._h)), "orl_engine_create")
         self.n_runs = cfg.n_runs
         self.metric_names = [self.lib.orl_metric_name(self._h, i).decode() for i in range(self.lib.orl_num_metrics(self._h))]
+        # a step that ran but raised a health flag: warn once per new flag (EngineHealthWarning), or raise when strict
+        self.strict_health = os.environ.get("ORL_STRICT_HEALTH", "0") == "1"
+        self._health_seen = 0
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -328,14 +348,51 @@ class Engine:
             n.on_device = 1 if on_device else 0
             npz = C.byref(n)
         m = np.zeros((self.n_runs, MAX_METRICS), dtype=np.float32)
-        _check(self.lib.orl_step(self._h, bp, npz, m.ctypes.data), "orl_step")
+        self._check_step(self.lib.orl_step(self._h, bp, npz, m.ctypes.data), "orl_step")
         return m[:, :len(self.metric_names)]
 
     def learn_n(self, n_steps: int):
         m = np.zeros((self.n_runs, MAX_METRICS), dtype=np.float32)
         ms = C.c_float()
-        _check(self.lib.orl_learn_n(self._h, n_steps, m.ctypes.data, C.byref(ms)), "orl_learn_n")
+        self._check_step(self.lib.orl_learn_n(self._h, n_steps, m.ctypes.data, C.byref(ms)), "orl_learn_n")
         return m[:, :len(self.metric_names)], ms.value
+
+    # ---- health (include/orl_engine.h: ORL_HEALTH_*) ----
+    def _check_step(self, rc: int, what: str):
+        if rc == RC_UNHEALTHY:
+            self._report_health(what)
+        else:
+            _check(rc, what)
+
+    def _report_health(self, what: str):
+        flags = int(np.bitwise_or.reduce(self.health()))
+        if self.strict_health:
+            raise EngineHealthError(f"{what}: {last_error()}")
+        if flags & ~self._health_seen:
+            warnings.warn(f"{what}: {last_error()}", EngineHealthWarning, stacklevel=3)
+        self._health_seen |= flags
+
+    def health(self) -> np.ndarray:
+        """Sticky per-run flags (HEALTH_* bits) as of the last step / learn_n / health_check."""
+        f = np.zeros(self.n_runs, dtype=np.uint32)
+        if self.lib.orl_health(self._h, f.ctypes.data) < 0:
+            raise RuntimeError(f"orl_health failed: {last_error()}")
+        return f
+
+    def health_check(self) -> np.ndarray:
+        """Scans the last step's split-precision operands (inputs, stored hidden activations, parameters) for the fp16-plane range on
+        top of what the steps themselves recorded; warns / raises like a step does.  One pass over the workspaces: per epoch, not per step."""
+        f = np.zeros(self.n_runs, dtype=np.uint32)
+        rc = self.lib.orl_health_check(self._h, f.ctypes.data)
+        if rc < 0:
+            raise RuntimeError(f"orl_health_check failed: {last_error()}")
+        if rc:
+            self._report_health("orl_health_check")
+        return f
+
+    def health_clear(self):
+        _check(self.lib.orl_health_clear(self._h), "orl_health_clear")
+        self._health_seen = 0
 
     def step_count(self) -> int:
         return self.lib.orl_step_count(self._h)

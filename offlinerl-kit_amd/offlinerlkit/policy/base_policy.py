@@ -444,6 +444,15 @@ class EnginePolicy(BasePolicy):
         self.last_learn_n_ms = ms
         return self._result(m)
 
+    def check_health(self):
+        """Per-run health flags of the bound engine (``_engine.HEALTH_*``: non-finite loss / gradient, an operand beyond the operand range
+        of split precision) after a range scan of the last step's operands; warns (``EngineHealthWarning``) or raises when the engine is
+        strict.  The reference has no counterpart: its diverged runs show as nan losses, which the engine's integer-view ReLU can mask.
+        ``MFPolicyTrainer`` calls it once per epoch."""
+        if self._eng is None:
+            return None
+        return self._eng.health_check()
+
     def run_state_dict(self, run: int) -> Dict[str, torch.Tensor]:
         """``state_dict()`` of one run (a copy; the live modules keep pointing at the run selected before)."""
         cur = max(self._cur_run, 0)

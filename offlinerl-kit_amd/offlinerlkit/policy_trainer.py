@@ -52,6 +52,7 @@ class MFPolicyTrainer:
             means = self.policy.learn_n(self._step_per_epoch, self.buffer, self._batch_size)
             for k, v in means.items():
                 self.logger.logkv(k, v)
+            self._check_health()
             return self._step_per_epoch
         it = range(self._step_per_epoch)
         if self._progress:
@@ -64,7 +65,14 @@ class MFPolicyTrainer:
                 it.set_postfix(**loss)
             for k, v in loss.items():
                 self.logger.logkv_mean(k, v)
+        self._check_health()
         return self._step_per_epoch
+
+    def _check_health(self) -> None:
+        """once per epoch: the engine's range / non-finite scan (EnginePolicy.check_health warns or raises); other policies have none"""
+        check = getattr(self.policy, "check_health", None)
+        if callable(check):
+            check()
 
     def _gather(self, kv: Dict[str, float]) -> None:
         """End-of-epoch metric all-gather: every rank contributes its metric vector, rank 0 logs ``rank<i>/<key>``."""
