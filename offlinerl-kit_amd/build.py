@@ -20,7 +20,7 @@ GEMM_H = ["gemm.h", "gemm_kernel.h"]
 WS_H = ["gemm.h", "ws_gemm.h", "ws_device.h"]
 # translation unit -> headers it depends on
 UNITS = {
-    "engine.hip": ["engine.h", "gemm.h", "ws_gemm.h", "small_fwd.h", "kernels.h", "algo_cql.inc", "algo_iql.inc", "algo_td3bc.inc", "algo_edac.inc", "algo_sac.inc", "algo_mcq.inc", ABI],
+    "engine.hip": ["engine.h", "gemm.h", "ws_gemm.h", "small_fwd.h", "small_bwd.h", "sample.h", "scalars.h", "kernels.h", "algo_cql.inc", "algo_iql.inc", "algo_td3bc.inc", "algo_edac.inc", "algo_sac.inc", "algo_mcq.inc", ABI],
     "gemm_inst_fwd.hip": GEMM_H,
     "gemm_inst_plain.hip": GEMM_H,
     "gemm_inst_rank1.hip": GEMM_H,
@@ -29,7 +29,8 @@ UNITS = {
     "ws_fwd.hip": WS_H,
     "ws_dgrad.hip": WS_H,
     "ws_wgrad.hip": WS_H,
-    "small_fwd.hip": ["small_fwd.h", "gemm.h"],
+    "small_fwd.hip": ["small_fwd.h", "sample.h", "gemm.h"],
+    "small_bwd.hip": ["small_bwd.h", "scalars.h", "gemm.h"],
 }
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 

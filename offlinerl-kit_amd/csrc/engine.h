@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "ws_gemm.h"
 #include "small_fwd.h"
+#include "small_bwd.h"
 
 namespace orl {
 
@@ -117,6 +118,11 @@ struct Engine {
   Hyper* hyper = nullptr;
   Hyper hyper_host;
   unsigned long long* gstep = nullptr;
+  // CQL advances the counter without a k_tick node: k_prepare reads gstep_pre and copies it to gstep (read by every later kernel of the
+  // step), the loss kernel's finishing lane writes gstep_pre = gstep + 1 (kernels.h: PrepP::gstep_publish, CqlLossP::gstep_next)
+  unsigned long long* gstep_pre = nullptr;
+  bool tick_folded = false;
+  bool fuse_small = true;      // few-runs fusions (sampling epilogue of the one-launch forward, step counter without k_tick, fused actor phase); ORL_FUSE_SMALL=0: the separate launches (A/B runs, cross-check tests)
   unsigned long long step_host = 0;
   float *metrics_last = nullptr, *metrics_sum = nullptr;
   int nm = 0;
@@ -174,6 +180,7 @@ struct Engine {
   float* gscale_slot();              // next slot for a seed kernel that publishes the scale itself (GradScaleP-free path); null at precision 0
   float* gscale_inv_b = nullptr;     // [R] constant scale of seeds whose entries are +-1/B (actor-loss dq)
   unsigned int* cql_ticket = nullptr;  // [R] arrival counters of k_cql_loss_rows
+  float* aloss_part = nullptr;         // [R][SB_MAXGROUPS][2] per-row-group loss sums of the fused actor update (small_bwd.h)
   // health (include/orl_engine.h: ORL_HEALTH_*): device words raised by kernels (k_adam: non-finite gradient; k_range_scan), the sticky
   // host copy that also holds what the host finds in the metrics it reads back, and the matrices of the last enqueued step that enter
   // the MFMAs as fp16 planes with operand scale 1 (registered by linear_fwd / mlp_forward while the step is enqueued or captured)
@@ -211,10 +218,17 @@ struct Engine {
   void prof_begin(const char* name, double flops, double bytes = 0);
   void prof_end();
   int assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int rows, int rep);
-  int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
+  // jobs (optional): tanh-Gaussian sampling jobs on this pass's head rows; the one-launch forward runs them as its epilogue (*jobs_done = true),
+  // any other path leaves them to the caller's k_tanh_sample launch
+  int mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag,
+                  const SampleJob* jobs = nullptr, int njobs = 0, bool* jobs_done = nullptr);
+  // q = net(X) and G = dq / dX[:, gc0 : gc0 + gn] for a unit seed in ONE launch (small_fwd.h, QG mode); *done = false when the shape is not
+  // served (the caller then runs forward + loss + backward launches)
+  int mlp_qgrad(const Mat& X, int M, const NetRef& nr, const Mat& q, const Mat& G, int gc0, int gn, const char* tag, bool* done);
   // a pass nobody differentiates (target nets, the actor's action proposals for the critic loss): the weight-stationary launches keep
   // hidden activations they do not need themselves out of HBM (they are marked dead: a later reader fails loudly)
-  int mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag);
+  int mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag,
+                       const SampleJob* jobs = nullptr, int njobs = 0, bool* jobs_done = nullptr);
   bool fwd_only = false;       // set while mlp_forward_only enqueues
   // the same with nn.Dropout(p) behind every hidden ReLU (keep masks in `masks[i]`, [R][M][H_i]); layer by layer on the tiled kernels
   int mlp_forward_dropout(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag, float p,

@@ -869,10 +869,12 @@ int Engine::assemble(const Mat& obs, const Mat* act, const Mat& X, int row0, int
   return 0;
 }
 
-int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag) {
+int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag,
+                        const SampleJob* jobs, int njobs, bool* jobs_done) {
   const NetLayout& l = *nr.lay;
   const int Ln = l.L;
   std::string t = tag;
+  if (jobs_done) *jobs_done = false;
   // few batched rows (one to a few runs per engine): the whole pass as ONE launch (small_fwd.h) instead of layer 0 + layer 1 + tail
   if (small_fwd_on && Ln == 2 && !l.ens && !no_ws && !force_scalar && l.H[0] == SF_N && l.H[1] == SF_N && hs[0].pitch == SF_N && hs[1].pitch == SF_N &&
       (long)M * R * nr.nz1 <= small_fwd_max_rows) {
@@ -891,6 +893,10 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     }
     w.OUT = out.p; w.o_s0 = out.rs; w.o_s1 = out.cs; w.o_pitch = out.pitch; w.out_dim = l.out_dim;
     w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
+    if (fuse_small && jobs && jobs_done && njobs >= 1 && njobs <= 3 && nr.nz1 == 1 && l.out_dim == 2 * ad && ad <= 8 && out.pitch == l.out_dim) {
+      w.njobs = njobs; w.A = ad;
+      for (int i = 0; i < njobs; ++i) w.job[i] = jobs[i];
+    }
     if (small_fwd_supported(w)) {
       const int nz = R * nr.nz1;
       watch_range(X, M, w.in0, X.cs ? nr.nz1 : 1, tag);
@@ -900,6 +906,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
       hipError_t err = launch_small_fwd(w, nz, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("small_fwd launch ") + tag + ": " + hipGetErrorString(err));
+      if (w.njobs) *jobs_done = true;
       for (int i = 0; i < 2; ++i) {
         if (hs[i].bits) bits_live.erase(hs[i].bits);      // no packed masks from this path: the backward reads 1[h > 0] from the values
         if (fwd_only) vals_dead.insert(hs[i].p); else vals_dead.erase(hs[i].p);
@@ -917,10 +924,41 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
   return linear_fwd(hs[Ln - 1], M, nr, Ln, out, E_BIAS, nullptr, (t + ".tail").c_str());
 }
 
-int Engine::mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag) {
+int Engine::mlp_qgrad(const Mat& X, int M, const NetRef& nr, const Mat& q, const Mat& G, int gc0, int gn, const char* tag, bool* done) {
+  const NetLayout& l = *nr.lay;
+  *done = false;
+  if (!(fuse_small && small_fwd_on && l.L == 2 && !l.ens && !no_ws && !force_scalar && l.H[0] == SF_N && l.H[1] == SF_N && l.out_dim == 1 &&
+        (long)M * R * nr.nz1 <= small_fwd_max_rows)) return 0;
+  SmallFwdP w;
+  memset(&w, 0, sizeof(w));
+  w.X = X.p; w.x_s0 = X.rs; w.x_s1 = X.cs; w.x_pitch = X.pitch; w.in0 = l.layer_in(0);
+  w.W0 = nr.base + l.w_off[0]; w.w0_s0 = nr.rs; w.w0_s1 = l.w_ms[0];
+  w.b0 = nr.base + l.b_off[0]; w.b0_s0 = nr.rs; w.b0_s1 = l.b_ms[0];
+  w.W1 = nr.base + l.w_off[1]; w.w1_s0 = nr.rs; w.w1_s1 = l.w_ms[1];
+  w.b1 = nr.base + l.b_off[1]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[1];
+  w.Wt = nr.base + l.w_off[2]; w.wt_s0 = nr.rs; w.wt_s1 = l.w_ms[2];
+  w.bt = nr.base + l.b_off[2]; w.bt_s0 = nr.rs; w.bt_s1 = l.b_ms[2];
+  w.OUT = q.p; w.o_s0 = q.rs; w.o_s1 = q.cs; w.o_pitch = q.pitch; w.out_dim = 1;
+  w.G = G.p; w.g_s0 = G.rs; w.g_s1 = G.cs; w.g_pitch = G.pitch; w.gc0 = gc0; w.gn = gn;
+  w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
+  if (!small_fwd_supported(w)) return 0;
+  const int nz = R * nr.nz1;
+  watch_range(X, M, w.in0, X.cs ? nr.nz1 : 1, tag);
+  // forward (layer 0, layer 1, tail) + the unit-seed backward through layer 1 and the gn input columns of layer 0
+  prof_begin(tag, 2.0 * M * (double)nz * (SF_N * (double)(w.in0 + 1) + 2.0 * SF_N * SF_N + SF_N + (double)SF_N * gn),
+             4.0 * nz * (M * (double)(X.pitch + 1 + gn) + 2.0 * SF_N * SF_N + (double)SF_N * (w.in0 + 3)));
+  hipError_t err = launch_small_fwd(w, nz, stream);
+  prof_end();
+  if (err != hipSuccess) return fail(std::string("small_qgrad launch ") + tag + ": " + hipGetErrorString(err));
+  *done = true;
+  return 0;
+}
+
+int Engine::mlp_forward_only(const Mat& X, int M, const NetRef& nr, std::vector<Mat>& hs, const Mat& out, const char* tag,
+                             const SampleJob* jobs, int njobs, bool* jobs_done) {
   struct Scope { Engine* e; ~Scope() { e->fwd_only = false; } } scope{this};
   fwd_only = true;
-  return mlp_forward(X, M, nr, hs, out, tag);
+  return mlp_forward(X, M, nr, hs, out, tag, jobs, njobs, jobs_done);
 }
 
 int Engine::scale_inplace(const Mat& m, int rows, int cols, int nets, float s, const Mat* mask, const char* tag) {
@@ -1094,13 +1132,15 @@ int Engine::init(const orl_config& c) {
   grads = raw_alloc(sizeof(float) * (size_t)R * max_slab * P_train);
   scalars = (RunScalars*)raw_alloc(sizeof(RunScalars) * R);
   hyper = (Hyper*)raw_alloc(sizeof(Hyper));
-  gstep = (unsigned long long*)raw_alloc(sizeof(unsigned long long));
+  gstep = (unsigned long long*)raw_alloc(2 * sizeof(unsigned long long));
+  gstep_pre = gstep ? gstep + 1 : nullptr;
   gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
   gscale_inv_b = raw_alloc(sizeof(float) * (size_t)R);
   cql_ticket = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
+  aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 32));
   health = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
   health_host.assign(R, 0u);
-  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health) return fail("hipMalloc state");
+  if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health || !aloss_part) return fail("hipMalloc state");
   {
     std::vector<float> inv(R, orl_pow2_scale(1.0f / (float)c.batch_size));
     ORL_HIP(hipMemcpyAsync(gscale_inv_b, inv.data(), sizeof(float) * R, hipMemcpyHostToDevice, stream));
@@ -1124,6 +1164,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
+  { const char* f = getenv("ORL_FUSE_SMALL"); if (f) fuse_small = atoi(f) != 0; }
   { const char* f = getenv("ORL_SMALL_FWD_MAX"); if (f && atol(f) > 0) small_fwd_max_rows = atol(f); }
   { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
@@ -1145,6 +1186,7 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_MCQ: rc = mcq_build(); break;
   }
   if (rc) return rc;
+  { Mat lc; lc.p = aloss_part + (long)R * SB_MAXGROUPS * 2; lc.pitch = 32; taps["lab_clk"] = {lc, 1, 32}; }      // shader-clock stamps of lab builds (small_bwd.hip)
   for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ns.cols ? ns.cols : ad};      // the noise arrays of the last step
   nm = (int)metric_names.size();
   if (nm > ORL_MAX_METRICS) return fail("too many metrics");
@@ -1216,7 +1258,7 @@ int Engine::enqueue_prepare(bool sampling, bool devnoise) {
     j.block_end = blocks;
     p.job[p.njobs++] = j;
   }
-  if (p.njobs == 0) return 0;
+  if (p.njobs == 0) return tick_folded ? fail("prepare: no job to carry the step counter") : 0;
   p.blocks = blocks;
   if (sampling) {
     if (!buf || !buf->obs) return fail("no replay buffer attached (orl_engine_attach_buffer)");
@@ -1231,6 +1273,7 @@ int Engine::enqueue_prepare(bool sampling, bool devnoise) {
   p.b_act = W("b_act").p; p.ba_rs = W("b_act").rs; p.b_ap = AP;
   p.b_rew = W("b_rew").p; p.b_term = W("b_term").p; p.br_rs = W("b_rew").rs;
   p.B = B; p.seed = cfg.seed; p.gstep = gstep; p.lo = cfg.act_low; p.hi = cfg.act_high;
+  if (tick_folded) { p.gstep = gstep_pre; p.gstep_publish = gstep; }
   ORL_LAUNCH("prepare", k_prepare, dim3((unsigned)blocks, R), dim3(256), p);
   return 0;
 }
@@ -1254,6 +1297,7 @@ int Engine::enqueue_step(int variant) {
     case ORL_ALGO_MCQ: rc = mcq_step(); break;
   }
   if (rc) return rc;
+  if (tick_folded) return 0;               // the step's own kernels advanced the counter
   hipLaunchKernelGGL(k_tick, dim3(1), dim3(1), 0, stream, gstep);
   return hipGetLastError() == hipSuccess ? 0 : fail("tick launch");
 }
@@ -1402,7 +1446,7 @@ int orl_reset_optimizers(orl_engine* h) {
   Engine& e = h->e;
   ORL_HIP(hipMemsetAsync(e.adam_m, 0, sizeof(float) * e.R * e.P_train, e.stream));
   ORL_HIP(hipMemsetAsync(e.adam_v, 0, sizeof(float) * e.R * e.P_train, e.stream));
-  ORL_HIP(hipMemsetAsync(e.gstep, 0, sizeof(unsigned long long), e.stream));
+  ORL_HIP(hipMemsetAsync(e.gstep, 0, 2 * sizeof(unsigned long long), e.stream));
   e.step_host = 0;
   ORL_HIP(hipStreamSynchronize(e.stream));
   return 0;
@@ -1432,9 +1476,9 @@ int orl_set_step_count(orl_engine* h, int64_t steps) {
   if (steps < 0) return fail("negative step count");
   ORL_HIP(hipSetDevice(e.dev));
   ORL_HIP(hipStreamSynchronize(e.stream));
-  const unsigned long long s = (unsigned long long)steps;
-  ORL_HIP(hipMemcpy(e.gstep, &s, sizeof(s), hipMemcpyHostToDevice));
-  e.step_host = s;
+  const unsigned long long s[2] = {(unsigned long long)steps, (unsigned long long)steps};      // (both cells: gstep and gstep_pre)
+  ORL_HIP(hipMemcpy(e.gstep, s, sizeof(s), hipMemcpyHostToDevice));
+  e.step_host = s[0];
   return 0;
 }
 

@@ -5,6 +5,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sample.h"
+#include "scalars.h"
+
 namespace orl {
 
 #ifndef ORL_HEALTH_NONFINITE_LOSS      // (include/orl_engine.h defines the same values for the C ABI)
@@ -39,21 +42,6 @@ __device__ inline void box_muller(uint32_t x, uint32_t y, float& n0, float& n1) 
   n0 = r * cosf(t); n1 = r * sinf(t);
 }
 
-// per-run scalars kept on the device so captured graphs replay without host patching
-struct RunScalars {
-  float log_alpha, la_m, la_v;          // SAC temperature + its Adam moments (run_cql.py:102-103)
-  float cql_log_alpha, cla_m, cla_v;    // CQL Lagrange multiplier (cql.py:57-58)
-  float alpha;                          // alpha used by the NEXT actor loss (sac.py:46 / cql.py:106)
-  float alpha_bwd;                      // alpha the current actor backward must use (pre-update value)
-  float cons_scale;                     // cql_alpha seen by the critic gradients (cql.py:170-178)
-  float last_actor_loss;                // TD3BC _last_actor_loss (td3.py:59)
-  float pad[6];
-};
-
-struct Hyper {                          // mutable hyper-parameters (orl_set_lr)
-  float lr[8];
-};
-
 // ------------------------------------------------------------------------------------------------
 // device step counter: Adam's t and the Philox offsets derive from it
 // ------------------------------------------------------------------------------------------------
@@ -66,12 +54,6 @@ __global__ void k_tick(unsigned long long* gstep) { *gstep += 1ull; }
 // 2^12 of headroom for the growth of a dz through the layers below and 2^-17 of room below before an entry's hi plane turns subnormal
 // (it then still carries 2^-24 absolute = 2^-27 of the largest entry).  One workgroup per run; max over every net's seed; exact.
 // ------------------------------------------------------------------------------------------------
-__device__ __host__ inline float orl_pow2_scale(float a) {     // 2^(3 - floor(log2 a)); 1 for 0 / non-finite
-  if (!(a > 0.f) || !(a < 3.0e38f)) return 1.f;
-  int e = ilogbf(a);
-  e = e < -100 ? -100 : (e > 100 ? 100 : e);
-  return ldexpf(1.0f, 3 - e);
-}
 // block-wide max over 256 threads; every thread receives it (NaNs are dropped by fmaxf)
 __device__ inline float block_max256(float v, float* sh4) {
 #pragma unroll
@@ -245,6 +227,9 @@ struct PrepP {
   const float *b_obs, *b_nobs, *b_act, *b_rew, *b_term; long bo_rs, ba_rs, br_rs; int b_op, b_ap;
   int B;
   unsigned long long seed; const unsigned long long* gstep; float lo, hi;
+  // step counter without a k_tick node (CQL): this kernel reads `gstep` = the PRE cell, which the step's loss kernel advances once every
+  // reader of the step is behind it (k_cql_loss_rows), and publishes it to the cell every later kernel of the step reads.  null: off.
+  unsigned long long* gstep_publish;
 };
 // np.random.randint(0, size, B) (buffer.py:98) on the device: one Philox call per (run, batch row), drawn ONCE per step and shared by
 // every consumer of that row (batch slots, actor / critic input rows and their N-fold repeats)
@@ -256,6 +241,7 @@ __device__ inline long long orl_draw_index(unsigned long long seed, int r, int b
 }
 __global__ void k_prepare(PrepP p) {
   const int r = blockIdx.y;
+  if (p.gstep_publish && blockIdx.x == 0 && r == 0 && threadIdx.x == 0) *p.gstep_publish = *p.gstep;
   int ji = 0;
   while (ji < p.njobs - 1 && (int)blockIdx.x >= p.job[ji].block_end) ++ji;       // block-uniform: scalar compares
   const PrepJob& jb = p.job[ji];
@@ -365,15 +351,6 @@ __global__ void k_assemble(AssembleP p) {
 // tanh-Gaussian sampling (dist_module.py:117-127, :17-42): head = [mu | log_sigma_raw] per base row.
 // One thread per output row; up to 3 jobs per launch (blockIdx.y), runs in blockIdx.z.
 // ------------------------------------------------------------------------------------------------
-#define ORL_LOG_SQRT_2PI 0.91893853320467274178f
-struct SampleJob {
-  int head_row0;     // first base row inside head
-  int rows;          // output rows
-  int rep;           // output row j uses base row head_row0 + j / rep
-  const float* eps;  long eps_rs;   // [R][rows][A] or null (deterministic)
-  float* dst;        long dst_rs; int dst_pitch, dst_col, dst_row0;  // actions -> dst[(dst_row0+j)*pitch + col + a]
-  float* logp;       long logp_rs;  // [R][rows] or null
-};
 struct SampleP {
   const float* head; long head_rs; int A;   // [R][rows_head][2A]
   SampleJob job[3];
@@ -392,14 +369,9 @@ __global__ void k_tanh_sample(SampleP p) {
   float term = 0.f;
   if (on) {
     const float* h = p.head + (long)r * p.head_rs + (long)(jb.head_row0 + j / jb.rep) * (2 * A);
-    const float mu = h[a];
-    const float ls = fminf(fmaxf(h[A + a], -5.0f), 2.0f);
-    const float sg = expf(ls);
-    const float u = jb.eps ? mu + sg * jb.eps[(long)r * jb.eps_rs + (long)j * A + a] : mu;
-    const float act = tanhf(u);
+    float act;
+    term = orl_tanh_sample(h[a], h[A + a], jb.eps ? jb.eps[(long)r * jb.eps_rs + (long)j * A + a] : 0.f, act);
     jb.dst[(long)r * jb.dst_rs + (long)(jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col + a] = act;
-    const float dm = u - mu;
-    term = (-(dm * dm) / (2.0f * (sg * sg)) - ls - ORL_LOG_SQRT_2PI) - logf((1.0f - act * act) + 1e-6f);
   }
   // fixed-order tree over the lane group (the reference sums the A terms of logp and of the Jacobian separately, dist_module.py:27-31;
   // the difference is fp32 reassociation of <= 32 terms)
@@ -417,16 +389,6 @@ __device__ inline float block_sum256(float v, float* sh) {
   __syncthreads();
   const float t = sh[0] + sh[1] + sh[2] + sh[3];
   return t;
-}
-
-// scalar Adam (log_alpha, cql_log_alpha): torch.optim.Adam single-tensor semantics
-__device__ inline void adam_scalar(float& p, float& m, float& v, float g, float lr, float b1, float b2, float eps,
-                                   unsigned long long t) {
-  m = m + (g - m) * (1.0f - b1);
-  v = v * b2 + (1.0f - b2) * g * g;
-  const double bc1 = 1.0 - pow((double)b1, (double)t), bc2 = 1.0 - pow((double)b2, (double)t);
-  const float step = (float)((double)lr / bc1), bc2s = (float)sqrt(bc2);
-  p -= step * (m / (sqrtf(v) / bc2s + eps));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +456,8 @@ __global__ void k_actor_loss(ActorLossP p) {
 // ------------------------------------------------------------------------------------------------
 struct HeadBwdP {
   const float* dxa; long dxa_rs, dxa_cs; int dxa_pitch; int K;  // [R][K][B][pitch] action-column grads
+  const float* dqa; long dqa_rs, dqa_cs;                           // non-null: dxa holds UNIT-seed gradients dq_c / da (the one-launch forward +
+                                                                   // backward, small_fwd.h QG mode); da = sum_c dqa[c][b] dxa[c][b]
   const float* head; long head_rs;                                // [R][B][2A]
   const float* eps; long eps_rs;                                  // [R][B][A]
   const float* xa; long xa_rs; int XP, od;                        // actions live in Xa[:, od:]
@@ -517,7 +481,8 @@ __global__ void k_head_bwd(HeadBwdP p) {
   float* dh = p.dhead + (long)r * p.dhead_rs + (long)b * 2 * A;
   for (int a = 0; a < A; ++a) {
     float da = 0.f;
-    for (int c = 0; c < p.K; ++c) da += p.dxa[(long)r * p.dxa_rs + (long)c * p.dxa_cs + (long)b * p.dxa_pitch + a];
+    for (int c = 0; c < p.K; ++c)
+      da += (p.dqa ? p.dqa[(long)r * p.dqa_rs + (long)c * p.dqa_cs + b] : 1.0f) * p.dxa[(long)r * p.dxa_rs + (long)c * p.dxa_cs + (long)b * p.dxa_pitch + a];
     const float lsr = h[A + a];
     const float sg = expf(fminf(fmaxf(lsr, -5.0f), 2.0f));
     const float act = x[a];
@@ -552,6 +517,7 @@ struct CqlLossP {
   float* part; int nblk;                   // partial sums [R][2][nblk][4] = (s_td, s_q, s_lse, max |dq|)
   unsigned int* ticket;                    // [R] arrival counters (zero between launches: the last arriver resets its own)
   float* gs_out;                           // split precision: dynamic scale of dq [R], or null
+  unsigned long long* gstep_next;          // the PRE cell of the step counter (PrepP::gstep_publish): run 0's finishing lane writes gstep + 1; null: k_tick does it
   int B, N, A;
   int Bc, Br;                              // COMBO: conservative rows repeat Bc batch rows; the -w mean Q term runs over the first Br rows
   float gamma, w, T, thr;
@@ -655,6 +621,7 @@ __global__ void k_cql_loss_rows(CqlLossP p) {
     p.metrics_last[(long)r * p.nm + slot] = loss; p.metrics_sum[(long)r * p.nm + slot] += loss;
   }
   if (p.gs_out) p.gs_out[r] = orl_pow2_scale(amax_all);
+  if (p.gstep_next && r == 0) *p.gstep_next = *p.gstep + 1ull;      // (k_prepare of this step is done, the next one has not started: stream order)
   if (p.with_lagrange) {
     const float l = -(cs * raw[0] + cs * raw[1]) * 0.5f;
     const float gate = (e_cla >= 0.f && e_cla <= 1e6f) ? 1.f : 0.f;

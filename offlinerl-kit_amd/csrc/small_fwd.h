@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "gemm.h"
+#include "sample.h"
 
 namespace orl {
 
@@ -28,6 +29,15 @@ struct SmallFwdP {
   float* OUT; long o_s0, o_s1; int o_pitch, out_dim;            // tail output [M][o_pitch], out_dim <= 16
   int M, nz1;
   int f32;                                                      // exact fp32 MFMA instead of the split 16-bit planes
+  // QG mode (G != nullptr; single-output nets, i.e. critics): forward AND backward of the row group for a unit seed in the same launch --
+  // OUT = q [M], G[m][a] = dq[m] / dx[m][gc0 + a], a < gn <= 8 (the action columns of the critic input: what the actor loss differentiates,
+  // cql.py:93-98).  The hidden activations never leave the workgroup: ReLU masks stay in registers, dz1 = w_tail (.) 1[h1 > 0] goes back into
+  // the LDS image the forward used, W1 streams through LDS a second time as 32-row chunks read with transposing LDS loads.
+  float* G; long g_s0, g_s1; int g_pitch, gc0, gn;
+  // optional epilogue: the tanh-Gaussian sampling jobs that consume this pass's head rows (k_tanh_sample's arithmetic on the rows the
+  // workgroup just produced: one kernel node less per actor pass).  nz1 == 1, out_dim == 2 A.
+  int njobs, A;
+  SampleJob job[3];
 };
 enum { SF_ROWS = 32, SF_N = 256, SF_NT = 512, SF_MAXOUT = 16 };
 
@@ -36,6 +46,8 @@ static inline bool small_fwd_supported(const SmallFwdP& p) {
   if (!aligned16(p.W1) || (p.w1_s0 & 3) || (p.w1_s1 & 3)) return false;
   if (p.H0 && (!aligned16(p.H0) || (p.h0_s0 & 3) || (p.h0_s1 & 3))) return false;
   if (p.H1 && (!aligned16(p.H1) || (p.h1_s0 & 3) || (p.h1_s1 & 3))) return false;
+  if (p.njobs && (p.njobs > 3 || p.nz1 != 1 || p.out_dim != 2 * p.A || p.A > 8 || p.G)) return false;
+  if (p.G && (p.out_dim != 1 || p.gn < 1 || p.gn > 8 || p.gc0 < 0 || p.gc0 + p.gn > p.in0 || p.g_pitch < p.gn)) return false;
   return true;
 }
 hipError_t launch_small_fwd(const SmallFwdP& p, int nz, hipStream_t st);      // small_fwd.hip

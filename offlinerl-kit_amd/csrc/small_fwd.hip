@@ -9,7 +9,11 @@ namespace orl {
 //   X    : the 32 input rows, K padded to 32, ones column at in0 (split: hi + lo [32][SF_WP], F32: [32][SF_WF])
 //   WT   : tail weights [16][256] fp32, b1 [256], bt [16]
 //   the cross-wave reduction of the tail reuses the W buffers after the last chunk
-enum { SF_AP = 264, SF_WP = 40, SF_AF = 260, SF_WF = 36 };
+//   QG mode, backward pass: the W buffers hold 32-ROW chunks of W1 (rows = output units n of the layer = the contraction index of the dgrad,
+//   all 256 input units j): split planes [32][256] 16-bit with 16-byte chunks XOR-swizzled per row (sf_toff: the transposing LDS reads and
+//   the 8-byte staging stores are both conflict free, as in ws_wgrad.hip), F32 [32][SF_TF] floats (pitch = 4 mod 64 banks: the four rows
+//   4 lq + e of one scalar fragment read sit 16 banks apart)
+enum { SF_AP = 264, SF_WP = 40, SF_AF = 260, SF_WF = 36, SF_TF = 260 };
 template <bool F32> static constexpr size_t sf_a_bytes() { return F32 ? (size_t)SF_ROWS * SF_AF * 4 : (size_t)2 * SF_ROWS * SF_AP * 2; }
 template <bool F32> static constexpr size_t sf_w_bytes() { return F32 ? (size_t)2 * SF_N * SF_WF * 4 : (size_t)2 * 2 * SF_N * SF_WP * 2; }
 template <bool F32> static constexpr size_t sf_x_bytes() { return F32 ? (size_t)SF_ROWS * SF_WF * 4 : (size_t)2 * SF_ROWS * SF_WP * 2; }
@@ -17,8 +21,23 @@ template <bool F32> static constexpr size_t sf_lds_bytes() {
   return sf_a_bytes<F32>() + sf_w_bytes<F32>() + sf_x_bytes<F32>() + (size_t)(SF_MAXOUT * SF_N + SF_N + SF_MAXOUT) * 4;
 }
 static_assert(sf_w_bytes<false>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4 && sf_w_bytes<true>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4, "tail reduction fits the chunk buffers");
+static_assert(sf_w_bytes<false>() >= (size_t)2 * 2 * SF_ROWS * SF_N * 2 && sf_w_bytes<true>() >= (size_t)2 * SF_ROWS * SF_TF * 4, "transposed chunks fit the chunk buffers");
+static_assert(sf_x_bytes<false>() >= (size_t)32 * SF_ROWS * 4 && sf_x_bytes<true>() >= (size_t)32 * SF_ROWS * 4, "QG: the q partial sums fit the input image");
 
-template <bool F32>
+// 16-bit element offset of the 8-byte piece (16-byte chunk `chunk`, half `half`) of row r of a [32][256] transposed-chunk plane
+__device__ __forceinline__ int sf_toff(int r, int chunk, int half) { return r * SF_N + ((chunk ^ (2 * (r & 7))) << 3) + (half << 2); }
+// transposing LDS read (gfx950 ds_read_b64_tr_b16): lane li of 16-lane group lq receives column col0 + li of rows row0 + 4 lq .. + 3
+__device__ __forceinline__ s16x4 sf_tr(const hx_t* img, int row0, int col0, int lane) {
+  const int li = lane & 15, lq = lane >> 4, row = row0 + 4 * lq + (li >> 2), col = col0 + 4 * (li & 3);
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(img + sf_toff(row, col >> 3, (col >> 2) & 1)));
+}
+__device__ __forceinline__ hx8 sf_cat(s16x4 x, s16x4 y) {
+  hx8 r;
+  *(s16x4*)&r = x; *((s16x4*)&r + 1) = y;
+  return r;
+}
+
+template <bool F32, bool QG>
 __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
   unsigned char* sA = sf_smem;
@@ -77,6 +96,33 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     }
   };
 
+  // QG: chunk c of the backward pass = rows 32 c .. 32 c + 31 of W1 (1 KB each); thread t moves the float4 (row (t + 512 i) >> 6, columns
+  // 4 ((t + 512 i) & 63) ..).  It is requested into wr[c + 1] as soon as the forward has stored that register set to LDS, so the whole
+  // second pass over W1 (L2 hits) is in flight while the forward still computes.
+  auto load_chunkT = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + SF_NT * i;
+      wr[c + 1][i] = *(const f32x4*)&W1g[(long)(32 * c + (e >> 6)) * SF_N + 4 * (e & 63)];
+    }
+  };
+  auto store_chunkT = [&](int c) __attribute__((always_inline)) {
+    const int buf = c & 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + SF_NT * i, r = e >> 6, col = 4 * (e & 63);
+      if constexpr (F32) *(f32x4*)((float*)sW + ((long)buf * SF_ROWS + r) * SF_TF + col) = wr[c + 1][i];
+      else {
+        hx_t* th = (hx_t*)sW + (long)buf * 2 * SF_ROWS * SF_N;
+        hx4 h, l;
+        orl_split4(wr[c + 1][i] * ORL_WSCALE, h, l);
+        const int o = sf_toff(r, col >> 3, (col >> 2) & 1);
+        *(hx4*)(th + o) = h;
+        *(hx4*)(th + SF_ROWS * SF_N + o) = l;
+      }
+    }
+  };
+
   // ---- prologue: EVERY global load of the launch is issued before the first LDS store (one exposed memory latency): input rows (ones
   // column at in0, zero beyond), tail constants, all nine weight chunks ----
   float xs[2];
@@ -100,6 +146,12 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     }
   }
   const float b1v = b1g[tid & (SF_N - 1)], btv = btg[tid < p.out_dim ? tid : 0];
+  float* sW0A = sWT + SF_N;                          // QG: [256][8] first-layer weights of the gn differentiated input columns (out_dim == 1: the tail weights use one row of sWT)
+  float w0a[8];
+  if constexpr (QG) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) w0a[a] = (a < p.gn ? 1.f : 0.f) * W0g[(long)(tid & (SF_N - 1)) * p.in0 + p.gc0 + (a < p.gn ? a : 0)];
+  }
 #pragma unroll
   for (int c = 0; c <= 8; ++c) load_chunk(c);
 #pragma unroll
@@ -120,6 +172,12 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   }
   if (tid < SF_N) sB1[tid] = b1v;
   if (tid < p.out_dim) sBT[tid] = btv;
+  if constexpr (QG) {
+    if (tid < SF_N) {
+#pragma unroll
+      for (int a = 0; a < 8; ++a) sW0A[tid * 8 + a] = w0a[a];
+    }
+  }
   store_chunk(0);
   __syncthreads();
 
@@ -188,10 +246,14 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     }
   };
 
+  unsigned int m0 = 0;                               // QG: ReLU mask of this lane's 16 first-layer outputs, bit 4 (2 s + cb) + j
 #pragma unroll
   for (int c = 0; c <= 8; ++c) {
     compute(c);
-    if (c + 1 <= 8) store_chunk(c + 1);             // that buffer was last read by compute(c - 1): every wave has passed the barrier since
+    if (c + 1 <= 8) {
+      store_chunk(c + 1);                            // that buffer was last read by compute(c - 1): every wave has passed the barrier since
+      if constexpr (QG) load_chunkT(c);              // ... and its registers take chunk c of the backward pass
+    }
     if (c == 0) {
       // layer-0 epilogue (the bias came in through the ones column): ReLU, optional store, the A image of layer 1
 #pragma unroll
@@ -200,7 +262,10 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
         for (int cb = 0; cb < 2; ++cb) {
           f32x4 v = acc[s][cb] * inv_sc;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (QG) m0 |= (v[j] > 0.f ? 1u : 0u) << (4 * (2 * s + cb) + j);
+            v[j] = v[j] > 0.f ? v[j] : 0.f;
+          }
           const int m = 16 * s + li, n = ncol0 + 16 * cb + 4 * lq;
           if (H0g) *(f32x4*)&H0g[(long)m * SF_N + n] = v;
           if constexpr (F32) *(f32x4*)((float*)sA + m * SF_AF + n) = v;
@@ -230,6 +295,137 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
       if (H1g) *(f32x4*)&H1g[(long)m * SF_N + n] = x;
       v[s][cb] = x;
     }
+  if constexpr (QG) {
+    // ================= QG: q = h1 . w_tail + b, then the backward pass for a unit seed dL/dq = 1 =================
+    // q partial sums (this lane's eight columns) -> [wave * 4 + lq][row] in the dead input image; dz1 = w_tail (.) 1[h1 > 0] -> the A image
+    // (every wave has finished reading h0 from it: barrier at the end of the last chunk)
+    float* qred = (float*)sX;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float pd = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int m = 16 * s + li, n = ncol0 + 16 * cb + 4 * lq;
+        const f32x4 w = *(const f32x4*)&sWT[n];
+        pd += (v[s][cb][0] * w[0] + v[s][cb][1] * w[1]) + (v[s][cb][2] * w[2] + v[s][cb][3] * w[3]);
+        f32x4 d;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = v[s][cb][j] > 0.f ? w[j] : 0.f;
+        if constexpr (F32) *(f32x4*)((float*)sA + m * SF_AF + n) = d;
+        else {
+          hx4 h, l;
+          orl_split4(d * ORL_WSCALE, h, l);          // w_tail is weight-sized: the static weight scale
+          *(hx4*)((hx_t*)sA + m * SF_AP + n) = h;
+          *(hx4*)((hx_t*)sA + SF_ROWS * SF_AP + m * SF_AP + n) = l;
+        }
+      }
+      qred[(wave * 4 + lq) * SF_ROWS + 16 * s + li] = pd;
+    }
+    store_chunkT(0);
+    __syncthreads();
+    zero_acc();
+    // dz0[m][j] = sum_n dz1[m][n] W1[n][j]: chunk c covers n = 32 c .. 32 c + 31.  Same accumulator layout as the forward (lane holds
+    // C[m = 16 s + li][j = ncol0 + 16 cb + 4 lq + r]), so the first layer's mask bits apply to the registers as they are.
+    auto computeT = [&](int c) __attribute__((always_inline)) {
+      const int buf = c & 1;
+      if constexpr (F32) {
+        const float* tf = (const float*)sW + (long)buf * SF_ROWS * SF_TF;
+        const float* af = (const float*)sA + 32 * c;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          f32x4 fa[2];
+          float fw[2][4];
+#pragma unroll
+          for (int s = 0; s < 2; ++s) fa[s] = *(const f32x4*)&af[(16 * s + li) * SF_AF + 16 * t + 4 * lq];
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fw[cb][e] = tf[(16 * t + 4 * lq + e) * SF_TF + ncol0 + 16 * cb + li];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) acc[s][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fw[cb][e], fa[s][e], acc[s][cb], 0, 0, 0);
+        }
+      } else {
+        const hx_t* th = (const hx_t*)sW + (long)buf * 2 * SF_ROWS * SF_N;
+        const hx_t* tl = th + SF_ROWS * SF_N;
+        const hx_t* ah = (const hx_t*)sA + 32 * c;
+        const hx_t* al = ah + SF_ROWS * SF_AP;
+        // the 8 contraction values of a lane: n = 32 c + 4 lq + {0..3} and 32 c + 16 + 4 lq + {0..3} (what two transposing reads deliver;
+        // the k order inside one MFMA is free as long as both operands use the same one)
+        hx8 fah[2], fal[2], fwh[2], fwl[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int o = (16 * s + li) * SF_AP + 4 * lq;
+          fah[s] = __builtin_shufflevector(*(const hx4*)&ah[o], *(const hx4*)&ah[o + 16], 0, 1, 2, 3, 4, 5, 6, 7);
+          fal[s] = __builtin_shufflevector(*(const hx4*)&al[o], *(const hx4*)&al[o + 16], 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          fwh[cb] = sf_cat(sf_tr(th, 0, ncol0 + 16 * cb, lane), sf_tr(th, 16, ncol0 + 16 * cb, lane));
+          fwl[cb] = sf_cat(sf_tr(tl, 0, ncol0 + 16 * cb, lane), sf_tr(tl, 16, ncol0 + 16 * cb, lane));
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwl[cb], fah[s], acc[s][cb]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwh[cb], fal[s], acc[s][cb]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[s][cb] = ORL_MFMA_16x16x32(fwh[cb], fah[s], acc[s][cb]);
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      computeT(c);
+      if (c + 1 < 8) store_chunkT(c + 1);
+      __syncthreads();
+    }
+    // dz0 = (.) 1[h0 > 0]; G[m][a] = sum_j dz0[m][j] W0[j][gc0 + a]: per-lane partial sums over its eight columns, reduced in a fixed order
+    constexpr float inv_sc2 = F32 ? 1.0f : 1.0f / (ORL_WSCALE * ORL_WSCALE);
+    float* gred = (float*)sW;                        // [wave * 4 + lq][row][8]; the chunk buffers are dead (barrier above)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float pg[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) pg[a] = 0.f;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d = ((m0 >> (4 * (2 * s + cb) + j)) & 1u) ? acc[s][cb][j] * inv_sc2 : 0.f;
+          const float* w = &sW0A[(ncol0 + 16 * cb + 4 * lq + j) * 8];
+          const f32x4 wa = *(const f32x4*)w, wb = *(const f32x4*)(w + 4);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) { pg[a] += d * wa[a]; pg[4 + a] += d * wb[a]; }
+        }
+      float* o = &gred[(((wave * 4 + lq) * SF_ROWS) + 16 * s + li) * 8];
+      *(f32x4*)o = (f32x4){pg[0], pg[1], pg[2], pg[3]};
+      *(f32x4*)(o + 4) = (f32x4){pg[4], pg[5], pg[6], pg[7]};
+    }
+    __syncthreads();
+    {
+      const int r = tid >> 4, a = tid & 15;
+      if (a < p.gn) {
+        float x = 0.f;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) x += gred[(w * SF_ROWS + r) * 8 + a];      // fixed order
+        (p.G + z0 * p.g_s0 + z1 * p.g_s1)[((long)g * SF_ROWS + r) * p.g_pitch + a] = x;
+      } else if (a == 8) {
+        float x = sBT[0];
+#pragma unroll
+        for (int w = 0; w < 32; ++w) x += qred[w * SF_ROWS + r];                // fixed order
+        (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch] = x;
+      }
+    }
+    return;
+  }
   // every lane leaves the partial sums of its eight columns in LDS (no cross-lane shuffles: a chain of dependent ds_bpermute per output
   // cost the actor's 12-output tail ~3 us); 32 partials per (row, output) = 8 waves x 4 lane groups, summed in a fixed order below
   for (int o = 0; o < p.out_dim; ++o) {
@@ -245,6 +441,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     }
   }
   __syncthreads();
+  float* shead = (float*)sA;                         // [SF_ROWS][SF_MAXOUT] tail outputs of this row group (the A image is dead: barriers above)
   {
     const int r = tid >> 4, o = tid & 15;
     if (o < p.out_dim) {
@@ -252,20 +449,48 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
 #pragma unroll
       for (int w = 0; w < 32; ++w) a += red[(w * SF_ROWS + r) * SF_MAXOUT + o];      // fixed order
       (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch + o] = a;
+      shead[r * SF_MAXOUT + o] = a;
+    }
+  }
+  if (p.njobs == 0) return;                          // (kernel-uniform)
+  // ---- sampling epilogue (small_fwd.h): every job that draws from head rows of this group; k_tanh_sample's arithmetic and summation order ----
+  __syncthreads();
+  const int A = p.A;
+  for (int ji = 0; ji < p.njobs; ++ji) {
+    const SampleJob& jb = p.job[ji];
+    const int per_row = jb.rep * 8, total = SF_ROWS * per_row;              // 8 lanes per output row (A <= 8)
+    for (int t = tid; t < total; t += SF_NT) {                              // whole 8-lane groups enter or leave together
+      const int lr = t / per_row, rem = t - lr * per_row, jr = rem >> 3, a = rem & 7;
+      const int hb = g * SF_ROWS + lr - jb.head_row0;                       // base row relative to the job's first head row
+      const long j = (long)hb * jb.rep + jr;
+      const bool on = hb >= 0 && j < jb.rows && a < A;
+      float term = 0.f;
+      if (on) {
+        float act;
+        term = orl_tanh_sample(shead[lr * SF_MAXOUT + a], shead[lr * SF_MAXOUT + A + a], jb.eps ? jb.eps[z0 * jb.eps_rs + j * A + a] : 0.f, act);
+        jb.dst[z0 * jb.dst_rs + (jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col + a] = act;
+      }
+      for (int o = 4; o > 0; o >>= 1) term += __shfl_down(term, o, 8);
+      if (on && a == 0 && jb.logp) jb.logp[z0 * jb.logp_rs + j] = term;
     }
   }
 }
 
 hipError_t launch_small_fwd(const SmallFwdP& p, int nz, hipStream_t st) {
   static const hipError_t attr_err = [] {
-    hipError_t e = hipFuncSetAttribute((const void*)small_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<false>());
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)small_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<true>());
+    hipError_t e = hipFuncSetAttribute((const void*)small_fwd_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<false>());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)small_fwd_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<true>());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)small_fwd_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<false>());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)small_fwd_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf_lds_bytes<true>());
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(p.M / SF_ROWS, 1, nz), block(SF_NT);
-  if (p.f32) hipLaunchKernelGGL(small_fwd_kernel<true>, grid, block, sf_lds_bytes<true>(), st, p);
-  else hipLaunchKernelGGL(small_fwd_kernel<false>, grid, block, sf_lds_bytes<false>(), st, p);
+  if (p.G) {
+    if (p.f32) hipLaunchKernelGGL((small_fwd_kernel<true, true>), grid, block, sf_lds_bytes<true>(), st, p);
+    else hipLaunchKernelGGL((small_fwd_kernel<false, true>), grid, block, sf_lds_bytes<false>(), st, p);
+  } else if (p.f32) hipLaunchKernelGGL((small_fwd_kernel<true, false>), grid, block, sf_lds_bytes<true>(), st, p);
+  else hipLaunchKernelGGL((small_fwd_kernel<false, false>), grid, block, sf_lds_bytes<false>(), st, p);
   return hipGetLastError();
 }
 

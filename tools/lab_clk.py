@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Prints the shader-clock stamps a lab build (-DSB_LAB_CLOCK) of small_abwd_kernel leaves behind: python tools/lab_clk.py [precision]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "offlinerl-kit_amd")]
+import bench_workloads as bw
+from offlinerlkit import _engine
+prec = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+ds = bw.make_dataset(0, 100_000, 17, 6)
+buf = _engine.DeviceBuffer(17, 6, 0)
+buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+eng = bw.make_engine("cql", 1, prec, 0, 5)
+eng.attach_buffer(buf)
+eng.learn_n(20)
+for _ in range(3):
+    eng.learn_n(1)
+    c = eng.debug_read(0, "lab_clk").view(np.uint64)[:13].astype(np.int64)
+    d = np.diff(c)
+    print("total %d clk | " % (c[11] - c[0]) + " ".join("%d:%d" % (i + 1, x) for i, x in enumerate(d[:11])))
+    e = eng.debug_read(0, "lab_clk").view(np.uint64)[12:16].astype(np.int64)
+    print("   chunk 3 of the dgrad loop: compute %d, store %d, barrier %d" % tuple(np.diff(e)))
