@@ -162,7 +162,7 @@ struct Engine {
   long small_fwd_max_rows = 8192;   // measured: 8 / 16 runs per engine +4 % against the weight-stationary launch at 4096 .. 8192 rows, 32 runs (16384 rows) -1 % (ORL_SMALL_FWD_MAX)
   long ws_fwd_min_rows = 4096, ws_bwd_min_rows = 4096;   // batched rows from which the weight-stationary forward / dgrad kernels replace the tiled launches (ORL_WS_FWD_MIN / ORL_WS_BWD_MIN)
   long ws_dgrad_plain_min_rows = 40000;   // batched rows from which a middle layer's dgrad (+ dW0) runs on the plain weight-stationary kernel (ORL_WS_DGRAD_PLAIN_MIN overrides)
-  long ws_wgrad_min_rows = 40000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides)
+  long ws_wgrad_min_rows = 15000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides; round 4: 40 000 -> 15 000, the 15 872 critic rows of ONE run: 1 run +4.3 %, 2 runs +1.7 %, fp32 +7.4 % / +0.7 %)
   int ws_wgrad_min_m = 1024;        // ... and rows PER NET: a 256-row net is 8 row groups behind a 256 KB slab write -- the tiled wgrad is faster there
                                     // (IQL / TD3+BC at 128 runs: +1.2 %; ORL_WS_WGRAD_MIN_M overrides)
   bool ws_wgrad_rows_ok(int M, int nz) const { return (long)M * nz >= ws_wgrad_min_rows && M >= ws_wgrad_min_m; }
@@ -180,6 +180,7 @@ struct Engine {
   float* gscale_slot();              // next slot for a seed kernel that publishes the scale itself (GradScaleP-free path); null at precision 0
   float* gscale_inv_b = nullptr;     // [R] constant scale of seeds whose entries are +-1/B (actor-loss dq)
   unsigned int* cql_ticket = nullptr;  // [R] arrival counters of k_cql_loss_rows
+  int lab_slot = 0;                    // lab builds: which stamp block the next one-launch forward writes (reset per step)
   float* aloss_part = nullptr;         // [R][SB_MAXGROUPS][2] per-row-group loss sums of the fused actor update (small_bwd.h)
   // health (include/orl_engine.h: ORL_HEALTH_*): device words raised by kernels (k_adam: non-finite gradient; k_range_scan), the sticky
   // host copy that also holds what the host finds in the metrics it reads back, and the matrices of the last enqueued step that enter

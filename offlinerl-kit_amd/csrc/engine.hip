@@ -899,6 +899,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     }
     if (small_fwd_supported(w)) {
       const int nz = R * nr.nz1;
+      if (lab_slot < 4) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 16 + 12 * lab_slot++;
       watch_range(X, M, w.in0, X.cs ? nr.nz1 : 1, tag);
       if (!fwd_only) watch_range(hs[0], M, SF_N, nr.nz1, tag);      // (h1 meets the tail weights in fp32 vector arithmetic)
       prof_begin(tag, 2.0 * M * (double)nz * (SF_N * (double)(w.in0 + 1) + (double)SF_N * SF_N + (double)SF_N * l.out_dim),
@@ -943,6 +944,7 @@ int Engine::mlp_qgrad(const Mat& X, int M, const NetRef& nr, const Mat& q, const
   w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
   if (!small_fwd_supported(w)) return 0;
   const int nz = R * nr.nz1;
+  if (lab_slot < 4) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 16 + 12 * lab_slot++;
   watch_range(X, M, w.in0, X.cs ? nr.nz1 : 1, tag);
   // forward (layer 0, layer 1, tail) + the unit-seed backward through layer 1 and the gn input columns of layer 0
   prof_begin(tag, 2.0 * M * (double)nz * (SF_N * (double)(w.in0 + 1) + 2.0 * SF_N * SF_N + SF_N + (double)SF_N * gn),
@@ -1137,7 +1139,7 @@ int Engine::init(const orl_config& c) {
   gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
   gscale_inv_b = raw_alloc(sizeof(float) * (size_t)R);
   cql_ticket = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
-  aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 32));
+  aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 128));
   health = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
   health_host.assign(R, 0u);
   if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health || !aloss_part) return fail("hipMalloc state");
@@ -1186,7 +1188,7 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_MCQ: rc = mcq_build(); break;
   }
   if (rc) return rc;
-  { Mat lc; lc.p = aloss_part + (long)R * SB_MAXGROUPS * 2; lc.pitch = 32; taps["lab_clk"] = {lc, 1, 32}; }      // shader-clock stamps of lab builds (small_bwd.hip)
+  { Mat lc; lc.p = aloss_part + (long)R * SB_MAXGROUPS * 2; lc.pitch = 128; taps["lab_clk"] = {lc, 1, 128}; }      // shader-clock stamps of lab builds (small_bwd.hip)
   for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ns.cols ? ns.cols : ad};      // the noise arrays of the last step
   nm = (int)metric_names.size();
   if (nm > ORL_MAX_METRICS) return fail("too many metrics");
@@ -1287,7 +1289,7 @@ int Engine::step_variant() const {
 
 int Engine::enqueue_step(int variant) {
   int rc = -1;
-  gscale_next = 0; cur_gscale = nullptr;
+  gscale_next = 0; cur_gscale = nullptr; lab_slot = 0;
   switch (cfg.algo) {
     case ORL_ALGO_CQL: rc = cql_step(); break;
     case ORL_ALGO_IQL: rc = iql_step(); break;

@@ -38,6 +38,7 @@ struct SmallFwdP {
   // workgroup just produced: one kernel node less per actor pass).  nz1 == 1, out_dim == 2 A.
   int njobs, A;
   SampleJob job[3];
+  unsigned long long* lab_clk;                                  // lab builds (-DSB_LAB_CLOCK): shader-clock stamps of workgroup (0, 0, 0), else unused
 };
 enum { SF_ROWS = 32, SF_N = 256, SF_NT = 512, SF_MAXOUT = 16 };
 
@@ -47,6 +48,7 @@ static inline bool small_fwd_supported(const SmallFwdP& p) {
   if (p.H0 && (!aligned16(p.H0) || (p.h0_s0 & 3) || (p.h0_s1 & 3))) return false;
   if (p.H1 && (!aligned16(p.H1) || (p.h1_s0 & 3) || (p.h1_s1 & 3))) return false;
   if (p.njobs && (p.njobs > 3 || p.nz1 != 1 || p.out_dim != 2 * p.A || p.A > 8 || p.G)) return false;
+  for (int i = 0; i < p.njobs; ++i) if (p.job[i].rep < 1 || p.job[i].rep > 16) return false;      // (the epilogue prefetches its noise: rep / 2 <= 8 values per thread and job)
   if (p.G && (p.out_dim != 1 || p.gn < 1 || p.gn > 8 || p.gc0 < 0 || p.gc0 + p.gn > p.in0 || p.g_pitch < p.gn)) return false;
   return true;
 }

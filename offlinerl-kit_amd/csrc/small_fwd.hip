@@ -7,18 +7,18 @@ namespace orl {
 //   A    : the 32 rows' current activation, all 256 k   (split: hi + lo planes [32][SF_AP], F32: [32][SF_AF])
 //   W    : two buffers of one 32-wide k chunk of the layer's weights for all 256 output units (split: hi + lo [256][SF_WP], F32: [256][SF_WF])
 //   X    : the 32 input rows, K padded to 32, ones column at in0 (split: hi + lo [32][SF_WP], F32: [32][SF_WF])
-//   WT   : tail weights [16][256] fp32, b1 [256], bt [16]
+//   WT   : tail weights [16][SF_TWP] fp32, b1 [256], bt [16]
 //   the cross-wave reduction of the tail reuses the W buffers after the last chunk
 //   QG mode, backward pass: the W buffers hold 32-ROW chunks of W1 (rows = output units n of the layer = the contraction index of the dgrad,
 //   all 256 input units j): split planes [32][256] 16-bit with 16-byte chunks XOR-swizzled per row (sf_toff: the transposing LDS reads and
 //   the 8-byte staging stores are both conflict free, as in ws_wgrad.hip), F32 [32][SF_TF] floats (pitch = 4 mod 64 banks: the four rows
 //   4 lq + e of one scalar fragment read sit 16 banks apart)
-enum { SF_AP = 264, SF_WP = 40, SF_AF = 260, SF_WF = 36, SF_TF = 260 };
+enum { SF_AP = 264, SF_WP = 40, SF_AF = 260, SF_WF = 36, SF_TF = 260, SF_TWP = 260 };
 template <bool F32> static constexpr size_t sf_a_bytes() { return F32 ? (size_t)SF_ROWS * SF_AF * 4 : (size_t)2 * SF_ROWS * SF_AP * 2; }
 template <bool F32> static constexpr size_t sf_w_bytes() { return F32 ? (size_t)2 * SF_N * SF_WF * 4 : (size_t)2 * 2 * SF_N * SF_WP * 2; }
 template <bool F32> static constexpr size_t sf_x_bytes() { return F32 ? (size_t)SF_ROWS * SF_WF * 4 : (size_t)2 * SF_ROWS * SF_WP * 2; }
 template <bool F32> static constexpr size_t sf_lds_bytes() {
-  return sf_a_bytes<F32>() + sf_w_bytes<F32>() + sf_x_bytes<F32>() + (size_t)(SF_MAXOUT * SF_N + SF_N + SF_MAXOUT) * 4;
+  return sf_a_bytes<F32>() + sf_w_bytes<F32>() + sf_x_bytes<F32>() + (size_t)(SF_MAXOUT * SF_TWP + SF_N + SF_MAXOUT) * 4;
 }
 static_assert(sf_w_bytes<false>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4 && sf_w_bytes<true>() >= (size_t)32 * SF_ROWS * SF_MAXOUT * 4, "tail reduction fits the chunk buffers");
 static_assert(sf_w_bytes<false>() >= (size_t)2 * 2 * SF_ROWS * SF_N * 2 && sf_w_bytes<true>() >= (size_t)2 * SF_ROWS * SF_TF * 4, "transposed chunks fit the chunk buffers");
@@ -37,6 +37,12 @@ __device__ __forceinline__ hx8 sf_cat(s16x4 x, s16x4 y) {
   return r;
 }
 
+#ifdef SB_LAB_CLOCK
+#define SF_STAMP(i) do { if (p.lab_clk && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) p.lab_clk[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SF_STAMP(i) do { } while (0)
+#endif
+
 template <bool F32, bool QG>
 __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sf_smem[];
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   unsigned char* sW = sA + sf_a_bytes<F32>();
   unsigned char* sX = sW + sf_w_bytes<F32>();
   float* sWT = (float*)(sX + sf_x_bytes<F32>());
-  float* sB1 = sWT + SF_MAXOUT * SF_N;
+  float* sB1 = sWT + SF_MAXOUT * SF_TWP;
   float* sBT = sB1 + SF_N;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int g = blockIdx.x, z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
@@ -57,6 +63,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   const float* __restrict__ Wtg = p.Wt + z0 * p.wt_s0 + z1 * p.wt_s1;
   const float* __restrict__ btg = p.bt + z0 * p.bt_s0 + z1 * p.bt_s1;
 
+  SF_STAMP(0);
   // ---- one 32-wide k chunk of weights: thread t moves the float4 (unit n = (t + 512 i) >> 3, k = 4 ((t + 512 i) & 7) ..), i = 0..3 ----
   // ALL nine chunks are requested up front (144 VGPRs): a workgroup has one 32-row group to do, so there is exactly one memory latency to
   // hide and nothing to hide it behind -- with one chunk in flight per iteration the launch took 15 - 19 us, nine exposed round trips
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     }
   }
   const float b1v = b1g[tid & (SF_N - 1)], btv = btg[tid < p.out_dim ? tid : 0];
-  float* sW0A = sWT + SF_N;                          // QG: [256][8] first-layer weights of the gn differentiated input columns (out_dim == 1: the tail weights use one row of sWT)
+  float* sW0A = sWT + SF_TWP;                        // QG: [256][8] first-layer weights of the gn differentiated input columns (out_dim == 1: the tail weights use one row of sWT)
   float w0a[8];
   if constexpr (QG) {
 #pragma unroll
@@ -154,6 +161,30 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
   }
 #pragma unroll
   for (int c = 0; c <= 8; ++c) load_chunk(c);
+  // sampling epilogue: thread (head row lr = tid >> 4, half = (tid >> 3) & 1, action a = tid & 7) takes output rows jr = half + 2 it of
+  // its head row (no index divisions); the noise values are requested HERE, behind every other load of the launch (inside the epilogue
+  // each of up to 11 iterations waited out its own round trip: 16 000 clocks for the three jobs of the [s; s'] pass)
+  constexpr int SF_EIT = 8;
+  auto sample_item = [&](const SampleJob& jb, int it, long& j) __attribute__((always_inline)) {
+    const int jr = ((tid >> 3) & 1) + 2 * it;
+    const int hb = g * SF_ROWS + (tid >> 4) - jb.head_row0;                 // base row relative to the job's first head row
+    j = (long)hb * jb.rep + jr;
+    return hb >= 0 && jr < jb.rep && j < jb.rows && (tid & 7) < p.A;
+  };
+  float ev[3][SF_EIT];
+  if constexpr (!QG) {
+#pragma unroll
+    for (int ji = 0; ji < 3; ++ji)
+#pragma unroll
+      for (int it = 0; it < SF_EIT; ++it) {
+        ev[ji][it] = 0.f;
+        if (ji < p.njobs && 2 * it < p.job[ji].rep) {                       // (uniform)
+          long j;
+          const bool on = sample_item(p.job[ji], it, j);
+          if (p.job[ji].eps) ev[ji][it] = (on ? 1.f : 0.f) * p.job[ji].eps[z0 * p.job[ji].eps_rs + (on ? j * p.A + (tid & 7) : 0)];
+        }
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + SF_NT * i, r = e >> 5, k = e & 31;
@@ -168,7 +199,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = 4 * (tid + SF_NT * i);
-    if (e < nwt) *(f32x4*)&sWT[e] = wts[i];
+    if (e < nwt) *(f32x4*)&sWT[(e >> 8) * SF_TWP + (e & (SF_N - 1))] = wts[i];
   }
   if (tid < SF_N) sB1[tid] = b1v;
   if (tid < p.out_dim) sBT[tid] = btv;
@@ -178,8 +209,10 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
       for (int a = 0; a < 8; ++a) sW0A[tid * 8 + a] = w0a[a];
     }
   }
+  SF_STAMP(1);
   store_chunk(0);
   __syncthreads();
+  SF_STAMP(2);
 
   f32x4 acc[2][2];
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -281,6 +314,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
     __syncthreads();
   }
 
+  SF_STAMP(3);
   // ---- layer-1 epilogue: bias, ReLU, optional store; tail = dot products of the wave's 32 columns, reduced across the eight waves ----
   float* red = (float*)sW;                           // [wave][lane group][row][SF_MAXOUT]; the chunk buffers are dead (barrier above)
   f32x4 v[2][2];
@@ -321,8 +355,10 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
       }
       qred[(wave * 4 + lq) * SF_ROWS + 16 * s + li] = pd;
     }
+    SF_STAMP(4);
     store_chunkT(0);
     __syncthreads();
+    SF_STAMP(5);
     zero_acc();
     // dz0[m][j] = sum_n dz1[m][n] W1[n][j]: chunk c covers n = 32 c .. 32 c + 31.  Same accumulator layout as the forward (lane holds
     // C[m = 16 s + li][j = ncol0 + 16 cb + 4 lq + r]), so the first layer's mask bits apply to the registers as they are.
@@ -387,6 +423,7 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
       if (c + 1 < 8) store_chunkT(c + 1);
       __syncthreads();
     }
+    SF_STAMP(6);
     // dz0 = (.) 1[h0 > 0]; G[m][a] = sum_j dz0[m][j] W0[j][gc0 + a]: per-lane partial sums over its eight columns, reduced in a fixed order
     constexpr float inv_sc2 = F32 ? 1.0f : 1.0f / (ORL_WSCALE * ORL_WSCALE);
     float* gred = (float*)sW;                        // [wave * 4 + lq][row][8]; the chunk buffers are dead (barrier above)
@@ -424,56 +461,89 @@ __global__ __launch_bounds__(SF_NT) void small_fwd_kernel(const SmallFwdP p) {
         (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch] = x;
       }
     }
+    SF_STAMP(7);
     return;
   }
-  // every lane leaves the partial sums of its eight columns in LDS (no cross-lane shuffles: a chain of dependent ds_bpermute per output
-  // cost the actor's 12-output tail ~3 us); 32 partials per (row, output) = 8 waves x 4 lane groups, summed in a fixed order below
-  for (int o = 0; o < p.out_dim; ++o) {
+  float* shead = (float*)sA;                         // [SF_ROWS][SF_MAXOUT] tail outputs of this row group (the A image is dead: barriers above)
+  if (p.out_dim > 1) {
+    // multi-output head (the actor's [mu | log sigma]): out[m][o] = sum_n h1[m][n] Wt[o][n] on the exact fp32 MFMA.  The wave's own 32
+    // columns are the contraction: step (cb, r) takes k slot lq <-> n = ncol0 + 16 cb + 4 lq + r, so the B operand B[k][j = m] is this lane's
+    // own accumulator register v[s][cb][r] and A[i = o][k] one float of the padded tail-weight image.  16 MFMAs per wave; the eight waves'
+    // partial sums meet in LDS.  (As per-lane dot products the 12 outputs took 8 200 clocks: 48 16-byte LDS reads per lane.)
+    f32x4 tacc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) tacc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = sWT[li * SF_TWP + ncol0 + 16 * cb + 4 * lq + r];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) tacc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, v[s][cb][r], tacc[s], 0, 0, 0);
+      }
+    // lane holds D[o = 4 lq + r][m = 16 s + li]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) *(f32x4*)&red[((wave * SF_ROWS) + 16 * s + li) * SF_MAXOUT + 4 * lq] = tacc[s];
+    SF_STAMP(4);
+    __syncthreads();
+    const int r = tid >> 4, o = tid & 15;
+    if (o < p.out_dim) {
+      float a = sBT[o];
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += red[(w * SF_ROWS + r) * SF_MAXOUT + o];       // fixed order
+      (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch + o] = a;
+      shead[r * SF_MAXOUT + o] = a;
+    }
+  } else {
+    // single output: every lane leaves the partial sum of its eight columns in LDS; 32 partials per row = 8 waves x 4 lane groups, summed
+    // in a fixed order below
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       float pd = 0.f;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        const f32x4 w = *(const f32x4*)&sWT[o * SF_N + ncol0 + 16 * cb + 4 * lq];
+        const f32x4 w = *(const f32x4*)&sWT[ncol0 + 16 * cb + 4 * lq];
         pd += (v[s][cb][0] * w[0] + v[s][cb][1] * w[1]) + (v[s][cb][2] * w[2] + v[s][cb][3] * w[3]);
       }
-      red[(((wave * 4 + lq) * SF_ROWS) + 16 * s + li) * SF_MAXOUT + o] = pd;
+      red[((wave * 4 + lq) * SF_ROWS) + 16 * s + li] = pd;
     }
-  }
-  __syncthreads();
-  float* shead = (float*)sA;                         // [SF_ROWS][SF_MAXOUT] tail outputs of this row group (the A image is dead: barriers above)
-  {
-    const int r = tid >> 4, o = tid & 15;
-    if (o < p.out_dim) {
-      float a = sBT[o];
+    SF_STAMP(4);
+    __syncthreads();
+    if (tid < SF_ROWS) {
+      float a = sBT[0];
 #pragma unroll
-      for (int w = 0; w < 32; ++w) a += red[(w * SF_ROWS + r) * SF_MAXOUT + o];      // fixed order
-      (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + r) * p.o_pitch + o] = a;
-      shead[r * SF_MAXOUT + o] = a;
+      for (int w = 0; w < 32; ++w) a += red[w * SF_ROWS + tid];                       // fixed order
+      (p.OUT + z0 * p.o_s0 + z1 * p.o_s1)[((long)g * SF_ROWS + tid) * p.o_pitch] = a;
     }
   }
+  SF_STAMP(5);
   if (p.njobs == 0) return;                          // (kernel-uniform)
   // ---- sampling epilogue (small_fwd.h): every job that draws from head rows of this group; k_tanh_sample's arithmetic and summation order ----
-  __syncthreads();
-  const int A = p.A;
-  for (int ji = 0; ji < p.njobs; ++ji) {
-    const SampleJob& jb = p.job[ji];
-    const int per_row = jb.rep * 8, total = SF_ROWS * per_row;              // 8 lanes per output row (A <= 8)
-    for (int t = tid; t < total; t += SF_NT) {                              // whole 8-lane groups enter or leave together
-      const int lr = t / per_row, rem = t - lr * per_row, jr = rem >> 3, a = rem & 7;
-      const int hb = g * SF_ROWS + lr - jb.head_row0;                       // base row relative to the job's first head row
-      const long j = (long)hb * jb.rep + jr;
-      const bool on = hb >= 0 && j < jb.rows && a < A;
-      float term = 0.f;
-      if (on) {
-        float act;
-        term = orl_tanh_sample(shead[lr * SF_MAXOUT + a], shead[lr * SF_MAXOUT + A + a], jb.eps ? jb.eps[z0 * jb.eps_rs + j * A + a] : 0.f, act);
-        jb.dst[z0 * jb.dst_rs + (jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col + a] = act;
+  if constexpr (!QG) {
+    __syncthreads();
+    const int A = p.A;
+#pragma unroll
+    for (int ji = 0; ji < 3; ++ji) {
+      if (ji >= p.njobs) break;                                             // (uniform)
+      const SampleJob& jb = p.job[ji];
+#pragma unroll
+      for (int it = 0; it < SF_EIT; ++it) {
+        if (2 * it >= jb.rep) break;                                        // (uniform) whole 8-lane groups enter or leave together
+        const int lr = tid >> 4, a = tid & 7;
+        long j;
+        const bool on = sample_item(jb, it, j);
+        float term = 0.f;
+        if (on) {
+          float act;
+          term = orl_tanh_sample(shead[lr * SF_MAXOUT + a], shead[lr * SF_MAXOUT + A + a], ev[ji][it], act);
+          jb.dst[z0 * jb.dst_rs + (jb.dst_row0 + j) * jb.dst_pitch + jb.dst_col + a] = act;
+        }
+        for (int o = 4; o > 0; o >>= 1) term += __shfl_down(term, o, 8);
+        if (on && a == 0 && jb.logp) jb.logp[z0 * jb.logp_rs + j] = term;
       }
-      for (int o = 4; o > 0; o >>= 1) term += __shfl_down(term, o, 8);
-      if (on && a == 0 && jb.logp) jb.logp[z0 * jb.logp_rs + j] = term;
     }
   }
+  SF_STAMP(6);
 }
 
 hipError_t launch_small_fwd(const SmallFwdP& p, int nz, hipStream_t st) {

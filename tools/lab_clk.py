@@ -20,3 +20,8 @@ for _ in range(3):
     print("total %d clk | " % (c[11] - c[0]) + " ".join("%d:%d" % (i + 1, x) for i, x in enumerate(d[:11])))
     e = eng.debug_read(0, "lab_clk").view(np.uint64)[12:16].astype(np.int64)
     print("   chunk 3 of the dgrad loop: compute %d, store %d, barrier %d" % tuple(np.diff(e)))
+    allc = eng.debug_read(0, "lab_clk").view(np.uint64).astype(np.int64)
+    for k, name in enumerate(("actor + sample", "critic qgrad", "actor2 + 3 sample jobs", "target critics")):
+        f = allc[16 + 12 * k: 16 + 12 * k + 8]
+        n = int((f > 0).sum())
+        print("   small_fwd %-24s total %6d | %s" % (name, f[n - 1] - f[0], " ".join("%d:%d" % (i + 1, x) for i, x in enumerate(np.diff(f[:n])))))
