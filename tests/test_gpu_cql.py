@@ -78,10 +78,16 @@ def test_cql_step_matches_oracle_and_reference(case):
                     # Adam moves a parameter by ~lr per step whatever |g| is (g/(|g|+eps)), so an element whose
                     # gradient is at the 1e-8 eps / rounding-noise level can legitimately differ by a fraction of lr
                     # per step: bound the bulk tightly and the outliers by the total possible travel.
-                    if True:
-                        assert d.mean() < 1e-6 * (k + 1), (nm, pn, d.mean())
-                        assert (d > tol).mean() < 1e-3, (nm, pn, (d > tol).mean())
-                        assert d.max() < 2 * 3e-4 * (k + 1), (nm, pn, d.max())
+                    # After the FIRST step (both sides started from the same parameters) at most 0.1 % of a tensor may sit beyond tol.  After
+                    # the last step the bar leaves room for two hidden units (2 / 256 of a tensor's rows): a unit whose pre-activations hover
+                    # around zero on many batch rows turns a last-bit difference of step 0 into a different ReLU mask and a different gradient
+                    # ROW from step 1 on.  Measured on cql_halfcheetah_maxq with two exact-fp32 summation orders of the SAME gradients (tiled
+                    # split-K wgrad, 32 slabs, vs one slab per workgroup, 128 slabs; step-0 gradients 3e-6 apart): unit 140 of critic1's second
+                    # layer and unit 168 of its first differ by up to 2.4 x at step 1; 0.5 % of W0 beyond tol at step 2, mean deviation 2.3e-6.
+                    frac_bar = 1e-3 if k == 0 else 1e-3 + 2.0 / 256.0
+                    assert d.mean() < 1e-6 * (k + 1), (nm, pn, d.mean())
+                    assert (d > tol).mean() < frac_bar, (nm, pn, k, (d > tol).mean())
+                    assert d.max() < 2 * 3e-4 * (k + 1), (nm, pn, d.max())
     eng.close()
 
 
@@ -301,6 +307,38 @@ def test_small_forward_kernel_matches_tiled_launches(monkeypatch, precision):
             for r in range(R):
                 assert rel_err(ma[r], mb[r], floor=1e-2) < loss_bar, (k, r, ma[r], mb[r])
         for nm in ("critic1", "critic2", "actor"):
+            a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
+            for pn in a:
+                d = np.abs(a[pn] - b1[pn])
+                assert d.mean() < mean_bar, (nm, pn, d.mean())
+                assert (d > 2e-5 + 1e-4 * np.abs(b1[pn]).max()).mean() < frac_bar, (nm, pn)
+    finally:
+        enga.close(); engb.close()
+
+
+@pytest.mark.parametrize("case", ["cql_halfcheetah", "cql_hopper"])
+@pytest.mark.parametrize("precision", [1, 0])
+def test_fused_actor_phase_matches_separate_launches(monkeypatch, precision, case):
+    """Few runs per engine (round 4): the actor phase of a CQL step is four launches -- the one-launch actor forward with the sampling
+    epilogue, critic forward + unit-seed backward (small_fwd_kernel<., QG>), actor loss + temperature step + head backward + actor backward
+    (small_abwd_kernel), Adam over one slab per 32-row group -- and the step counter advances without a k_tick node.  An engine created
+    with ORL_FUSE_SMALL=0 issues the separate launches (k_tanh_sample, k_actor_loss, two dgrad launches, k_head_bwd, five backward
+    launches, k_tick) for the same math.  Same inputs -> losses, alpha and updated parameters agree to rounding over the fixture's window,
+    both precisions, at the halfcheetah and hopper shapes (critic input 23 / 14 columns, actor head 12 / 6 outputs)."""
+    R = 2
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.setenv("ORL_FUSE_SMALL", "0")     # read at engine creation
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.delenv("ORL_FUSE_SMALL")
+    loss_bar, mean_bar, frac_bar = ((2e-5, 3e-6, 2e-3) if precision == 1 else (2e-6, 3e-7, 3e-4))
+    try:
+        for k, (b, n) in enumerate(zip(batches[:4], noises[:4])):
+            ma = enga.step(lead(b, R), lead(noise_list(n), R))
+            mb = engb.step(lead(b, R), lead(noise_list(n), R))
+            for r in range(R):
+                assert rel_err(ma[r], mb[r], floor=1e-2) < loss_bar, (k, r, ma[r], mb[r])
+        assert enga.step_count() == engb.step_count() == 4
+        for nm in ("actor", "critic1", "critic2"):
             a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
             for pn in a:
                 d = np.abs(a[pn] - b1[pn])
