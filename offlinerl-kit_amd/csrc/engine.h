@@ -211,9 +211,20 @@ struct Engine {
   int tq_scratch_nets = 2;
   int linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int col0, int ncols, const Mat* maskH, const Mat& dX, const char* tag,
                    const Mat* w0_X = nullptr, bool store_dx = true, int* w0_slabs = nullptr);
+  // recompute_X0 (layer 1 only): X = hs[0] was not stored by the forward pass (vals_dead); the plain output-stationary kernel rebuilds it
+  // from the net's input rows (WsWgradP::X0)
   int linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
                    const char* tag, int in_row0 = 0, int in_rows = -1, bool* fuse_tail = nullptr, int* slabs_out = nullptr,
-                   const float* x_dscale = nullptr);
+                   const float* x_dscale = nullptr, const Mat* recompute_X0 = nullptr);
+  // Three-layer nets on the weight-stationary kernels: do not store the first hidden activation, let the middle layer's wgrad rebuild it from
+  // the 24-column input (ws_wgrad_kernel<4>, ORL_WS_RECOMPUTE_H0=1).  OFF by default -- measured at 128 runs (round 4, one call): the forward
+  // drops 957 -> 790 us, but the wgrad's row loop is not HBM-bound enough to absorb 12 MFMAs + the ReLU / split of a 32 x 32 block per wave
+  // and group: 770 -> 1225 us (split, 42 spilled VGPRs next to the 128 accumulators; exact fp32, no spills: step 14.68 -> 14.86 ms);
+  // whole step 23.46k -> 22.78k steps/s.
+  bool recompute_h0 = false;
+  bool recompute_h0_ok(const NetLayout& l, int layer, int M, int nz) const {
+    return recompute_h0 && layer == 1 && l.L >= 3 && !l.ens && ws_precision_ok() && ws_wgrad_rows_ok(M, nz);
+  }
   int adam(int net, int nnets, int lr_slot, const std::vector<std::pair<long, int>>& segs, int target_net, unsigned long long t_div = 1);
   int polyak(int target_net, int src_net, int nnets);
   void prof_begin(const char* name, double flops, double bytes = 0);

@@ -465,7 +465,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       w.mb0 = X.bits; w.mb0_s0 = X.brs; w.mb0_s1 = X.bcs; w.mb0_g = X.bg;
       fused0 = ws_fwd01_supported(w) && aligned16(fuse_X0->p);
       if (!fused0) w.X0 = nullptr;
-      else if (fwd_only) w.x0_discard = 1;
+      else if (fwd_only || (!want_tail && recompute_h0_ok(l, layer, M, nz))) w.x0_discard = 1;      // (a three-layer net's middle-layer wgrad rebuilds h0 from the input rows)
     }
     if (fuse_X0 && !fused0) {      // layer 0 on its own, then this layer
       if (linear_fwd(*fuse_X0, M, nr, 0, X, E_BIAS_RELU, nullptr, tag0 ? tag0 : tag)) return -1;
@@ -724,12 +724,13 @@ static int wgrad_ksplit(int Mout, int Nout, int Krows, int nz, int cap) {
 
 // slabs_out: number of split-K slabs actually written (== ksplit unless the weight-stationary kernel chose its own decomposition)
 int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, int layer, int ksplit, int slab0, bool with_bias,
-                         const char* tag, int in_row0, int in_rows, bool* fuse_tail, int* slabs_out, const float* x_dscale) {
+                         const char* tag, int in_row0, int in_rows, bool* fuse_tail, int* slabs_out, const float* x_dscale, const Mat* recompute_X0) {
   const NetLayout& l = *nr.lay;
   const int in = l.layer_in(layer), out = l.layer_out(layer);
   if (in_rows < 0) in_rows = in;
   if (slab0 + ksplit > max_slab) return fail("wgrad: slab budget exceeded");
-  if (vals_dead.count(X.p)) return fail(std::string("wgrad ") + tag + ": the input activation was not stored by the forward pass");
+  const bool x_dead = vals_dead.count(X.p) > 0;
+  if (x_dead && !(recompute_X0 && layer == 1)) return fail(std::string("wgrad ") + tag + ": the input activation was not stored by the forward pass");
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.a_dscale = cur_gscale; p.b_dscale = x_dscale;      // split precision: A = dY^T of the current backward pass; B = X (an activation, or a gradient-like matrix with its own scale)
@@ -797,12 +798,18 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     memset(&w, 0, sizeof(w));
     w.dZ = dy.m.p; w.dz_s0 = dy.m.rs; w.dz_s1 = dy.m.cs; w.dz_pitch = dy.m.pitch;
     w.H0 = X.p; w.h0_s0 = X.rs; w.h0_s1 = X.cs; w.h0_pitch = X.pitch;
+    if (x_dead) {                                  // h0 = relu(X0 W0^T + b0) is rebuilt inside the launch
+      w.X0 = recompute_X0->p; w.x0_s0 = recompute_X0->rs; w.x0_s1 = recompute_X0->cs; w.x0_pitch = recompute_X0->pitch; w.in0 = l.layer_in(0);
+      w.W0 = nr.base + l.w_off[0]; w.w0_s0 = nr.rs; w.w0_s1 = l.w_ms[0]; w.w0_sn = l.layer_in(0); w.w0_sk = 1;
+      w.b0 = nr.base + l.b_off[0]; w.b0_s0 = nr.rs; w.b0_s1 = l.b_ms[0];
+    }
     w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);
-      prof_begin(tag, 2.0 * M * (double)in * (out + 1) * nz, nz * (4.0 * M * (double)(in + out) + 4.0 * per_z * out * (in + 1)));
+      prof_begin(tag, 2.0 * M * (double)in * (out + 1 + (x_dead ? w.in0 + 1 : 0)) * nz,
+                 nz * (4.0 * M * (double)((x_dead ? w.x0_pitch : in) + out) + 4.0 * per_z * out * (in + 1)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
@@ -810,6 +817,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       return 0;
     }
   }
+  if (x_dead) return fail(std::string("wgrad ") + tag + ": the input activation was not stored and the recomputing kernel does not serve this shape");
   if (dy.rank1 && vals_dead.count(dy.m.p)) return fail(std::string("wgrad ") + tag + ": the activation values were not stored by the forward pass");
   if (fuse_tail) {
     // the rank-1 kernel streams h and dq anyway: let it also emit the tail layer's dw / db (same split-K slabs)
@@ -1029,7 +1037,8 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
       bool fused = false;
       const bool top = rank1 && (i == L - 1);
       int slabs = ks[i];
-      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr, &slabs)) return -1;
+      if (e->linear_wgrad(cur, xin, M, nr, i, ks[i], 0, true, (t + ".wgrad" + std::to_string(i)).c_str(), 0, -1, top ? &fused : nullptr, &slabs, nullptr,
+                          i == 1 ? &X : nullptr)) return -1;
       ks[i] = slabs;
       if (top) {
         if (fused) ks[L] = ks[i];           // the tail gradients were written into the same split-K slabs
@@ -1167,6 +1176,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
   { const char* f = getenv("ORL_FUSE_SMALL"); if (f) fuse_small = atoi(f) != 0; }
+  { const char* f = getenv("ORL_WS_RECOMPUTE_H0"); if (f) recompute_h0 = atoi(f) != 0; }
   { const char* f = getenv("ORL_SMALL_FWD_MAX"); if (f && atol(f) > 0) small_fwd_max_rows = atol(f); }
   { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }

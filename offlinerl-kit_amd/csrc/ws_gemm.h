@@ -208,19 +208,27 @@ struct WsWgradP {
   //   dW[k][n] = sum_m dZ[m][k] * H0[m][n],  db[k] = sum_m dZ[m][k]
   // Same output-stationary structure; the A operand has a lo plane now (three products per block instead of two), no mask, no w_tail.
   const float* dZ; long dz_s0, dz_s1; int dz_pitch;
+  // RECOMPUTE variant of PLAIN (X0 != nullptr): H0 = relu(X0 W0^T + b0) was NOT stored by the forward pass (a three-layer net's first hidden
+  // activation: 2 GB written and 2 GB read per step at 128 runs for a matrix that 12 MFMAs per wave and row group rebuild from a 24-column
+  // input).  Every wave reproduces its own 32 columns of the group with the forward's instruction sequence (bit-identical values) straight
+  // into the H image.  in0 + 1 <= 32, x0_pitch <= 32.
+  const float* X0; long x0_s0, x0_s1; int x0_pitch, in0;
+  const float* W0; long w0_s0, w0_s1, w0_sn, w0_sk;
+  const float* b0; long b0_s0, b0_s1;
   int M, nz1, groups;
   int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of the split 16-bit planes
   const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq / dZ, one float per run (z0); null = 1
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
-static constexpr size_t ws_wgrad_lds_bytes(bool plain = false) {   // 2 buffers x {mask, G hi, G lo} (plain: {dZ hi, dZ lo, H hi, H lo}) + dq / ones blocks
-  return (size_t)2 * (plain ? 4 : 3) * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2;
+static constexpr size_t ws_wgrad_lds_bytes(bool plain = false, bool recompute = false) {   // 2 buffers x {mask, G hi, G lo} (plain: {dZ hi, dZ lo, H hi, H lo}) + dq / ones blocks (+ the narrow input rows)
+  return (size_t)2 * (plain ? 4 : 3) * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2 + (recompute ? sizeof(float) * 2 * WS_ROWS * WS_XLP : 0);
 }
 
 static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
   if (p.dZ) {
     if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS)) return false;
     if (!aligned16(p.dZ) || (p.dz_pitch & 3) || (p.dz_s0 & 3) || (p.dz_s1 & 3)) return false;
+    if (p.X0) return p.W0 && p.b0 && p.in0 + 1 <= 32 && p.in0 < p.x0_pitch + 1 && p.x0_pitch <= 32 && p.in0 <= p.x0_pitch && WS_ROWS * p.x0_pitch <= 2 * WS_NT;
     return aligned16(p.H0) && !(p.h0_pitch & 3) && !(p.h0_s0 & 3) && !(p.h0_s1 & 3);
   }
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.abits || p.ab_g != 8) return false;

@@ -149,10 +149,11 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
 
 // MODE 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators,
 //      3: PLAIN -- a materialised dZ instead of (mask, dq, w_tail): A gets a lo plane (three products per block), B = H0 itself
+//      4: PLAIN with H0 = relu(X0 W0^T + b0) recomputed per row group from the narrow input instead of streamed (WsWgradP::X0)
 template <int MODE>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
-  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3);
+  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3 || MODE == 4), RECOMP = (MODE == 4);
   constexpr int NPL = PLAIN ? 4 : 3;                                // LDS planes per buffer
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   hx_t* img = (hx_t*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]   (PLAIN: {dZ hi, dZ lo, H hi, H lo})
@@ -185,6 +186,76 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   float sdq[4];
   unsigned int sm_word;
   hx_t* dqimg = img + 2 * NPL * WW_IMG;                            // [buf][hi, lo][32 rows][16]: column 0 = dq (PLAIN: 1), others 0 (db1 operand)
+  // ---- RECOMP: first-layer fragments of this wave's 32 columns (K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond) and the
+  // staging of the narrow input rows -- ws_fwd_kernel<., L0>'s producer, writing into this kernel's H image ----
+  float* Xl = (float*)(dqimg + 2 * 2 * WS_ROWS * 16);               // [buf][32][WS_XLP]: hi plane in 16-bit slots 0..31, lo plane in 32..63 of a row
+  const float* __restrict__ X0g = RECOMP ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
+  hx8 b0h[2], b0l[2];
+  if (RECOMP) {
+    const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
+    const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = ncol0 + 16 * cb + li;
+      f32x4 a, b;
+      const float bn = b0g[n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                                  // clamped addresses and 0 / 1 factors, not guarded loads (ws_fwd.hip)
+        const int k0 = 8 * lq + j, k1 = k0 + 4;
+        const float w0 = W0g[(long)n * p.w0_sn + (long)(k0 < p.in0 ? k0 : p.in0 - 1) * p.w0_sk];
+        const float w1 = W0g[(long)n * p.w0_sn + (long)(k1 < p.in0 ? k1 : p.in0 - 1) * p.w0_sk];
+        a[j] = (k0 < p.in0 ? 1.f : 0.f) * w0 + (k0 == p.in0 ? 1.f : 0.f) * bn;
+        b[j] = (k1 < p.in0 ? 1.f : 0.f) * w1 + (k1 == p.in0 ? 1.f : 0.f) * bn;
+      }
+      ws_split8(a, b, b0h[cb], b0l[cb]);
+    }
+  }
+  const int xe = RECOMP ? WS_ROWS * p.x0_pitch : 0;
+  int xr[2], xc[2];
+  float sx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    xr[i] = RECOMP ? e / (RECOMP ? p.x0_pitch : 1) : 0; xc[i] = RECOMP ? e - xr[i] * p.x0_pitch : 0;
+    if (RECOMP && e >= xe) { xr[i] = 0; xc[i] = 32; }               // surplus threads: pad slots
+  }
+  auto loadX = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
+  };
+  auto storeX = [&](int xbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float x = (xc[i] == p.in0) ? 1.0f : sx[i];
+      hx_t* row = (hx_t*)(Xl + (xbuf * WS_ROWS + xr[i]) * WS_XLP);
+      const bool pad = xc[i] >= 32;
+      hx_t hh, ll;
+      orl_split1(x, hh, ll);
+      row[pad ? 64 : xc[i]] = hh;
+      row[pad ? 65 : 32 + xc[i]] = ll;
+    }
+  };
+  hx8 xah, xal;
+  auto prod_x = [&](int xbuf, int s) __attribute__((always_inline)) {
+    const hx_t* xrow = (const hx_t*)(Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP) + 8 * lq;
+    xah = *(const hx8*)xrow; xal = *(const hx8*)(xrow + 32);
+  };
+  // one 16 x 16 block of h0 of the group staged in Xl[xbuf] -> the H planes of image `buf` (the forward's three products and ReLU, bit for bit)
+  auto prod_block = [&](int buf, int s, int cb) __attribute__((always_inline)) {
+    hx_t* gh = img + (long)buf * NPL * WW_IMG + (NPL - 2) * WW_IMG;
+    hx_t* gl = gh + WW_IMG;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    v = ORL_MFMA_16x16x32(b0l[cb], xah, v);
+    v = ORL_MFMA_16x16x32(b0h[cb], xal, v);
+    v = ORL_MFMA_16x16x32(b0h[cb], xah, v);
+    orl_relu_mask4(v);
+    hx4 h, l;
+    orl_split4(v, h, l);
+    const int k = ncol0 + 16 * cb + 4 * lq;                          // the lane holds C[m = 16 s + li][n = k .. k + 3]
+    const int o = ww_off(16 * s + li, k >> 3, (k >> 2) & 1);
+    *(hx4*)(gh + o) = h;
+    *(hx4*)(gl + o) = l;
+  };
   // Global addresses = (uniform part: row group and piece, scalar ALU) + (per-thread part, computed once): the loop carries no vector
   // address arithmetic (64-bit multiplies cost a SIMD 4 - 7 cycles each, and vector instructions do not overlap with its MFMAs).
   const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
@@ -193,7 +264,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
     const long row0 = (long)g * WS_ROWS + 8 * i;                      // uniform: rows row0 + (tid >> 6)
-    s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
+    if (!RECOMP) s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
     if (TAILS || PLAIN) s1[i] = *(const f32x4*)&(H1g + row0 * h1_pitch)[vo_h1];
     if (!PLAIN) sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
@@ -226,9 +297,11 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     hx4 h, l;
     const int o = ww_off(r, kq >> 1, kq & 1);
     if (PLAIN) {
-      orl_split4(s0[i], h, l);
-      *(hx4*)(gh + o) = h;
-      *(hx4*)(gl + o) = l;
+      if (!RECOMP) {
+        orl_split4(s0[i], h, l);
+        *(hx4*)(gh + o) = h;
+        *(hx4*)(gl + o) = l;
+      }
       hx_t* zh = img + (long)buf * NPL * WW_IMG;
       orl_split4(s1[i] * gsc, h, l);
       *(hx4*)(zh + o) = h;
@@ -262,9 +335,25 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     if (tid < 2 * WS_ROWS) (dqimg + (long)(tid >> 5) * 2 * WS_ROWS * 16)[(tid & 31) * 16] = (hx_t)1.0f;
   }
   if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
+  if (RECOMP) for (int e = tid; e < 2 * WS_ROWS * WS_XLP; e += WS_NT) Xl[e] = 0.f;      // columns >= x0_pitch stay zero
   __syncthreads();
 
   const int g0 = blockIdx.x, gs = gridDim.x;
+  // RECOMP: the narrow rows of iteration j live in Xl[j & 1]; iteration `it` produces h0 of iteration it + 1 into the other image and stages
+  // the rows of iteration it + 2 where iteration it - 1 read its own
+  if (RECOMP && g0 < p.groups) {
+    loadX(g0);
+    storeX(0);
+    if (g0 + gs < p.groups) loadX(g0 + gs);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      prod_x(0, s);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) prod_block(0, s, cb);
+    }
+    if (g0 + gs < p.groups) storeX(1);
+  }
   if (g0 < p.groups) {
     load_group(g0);
     store_group(0);
@@ -344,6 +433,14 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
           if (more) store_piece(buf ^ 1, kp);
           if (more2) load_piece(g + 2 * gs, kp);
         }
+        if (RECOMP) {                                                // h0 of the next group: one block per trip behind the staging stores
+          if (kp == 0 && more2) loadX(g + 2 * gs);
+          if (kp >= 4 && more) {
+            if (!(kp & 1)) prod_x(buf ^ 1, (kp - 4) >> 1);
+            prod_block(buf ^ 1, (kp - 4) >> 1, kp & 1);
+          }
+          if (kp == 7 && more2) storeX(buf);
+        }
         if (kp == 5) {
           if (more) store_mask(buf ^ 1);
           if (more2) load_mask(g + 2 * gs);
@@ -356,7 +453,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
 
-  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
+  ww_finish<(MODE == 4 ? 3 : MODE)>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
 }
 
 // ---- exact-fp32 flavour (precision 0): the same output-stationary structure on v_mfma_f32_16x16x4_f32 ----
@@ -365,16 +462,19 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 // banks) puts the four rows of one read on disjoint banks.  32 rows = 8 MFMA k steps; two 16-row k blocks of the output are in flight
 // so that dependent MFMAs stay four instructions apart.
 enum { WW32_P = 272, WW32_IMG = WS_ROWS * WW32_P };
-static constexpr size_t ws_wgrad32_lds_bytes() { return sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS) > sizeof(float) * 17 * WS_K
-                                                        ? sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS) : sizeof(float) * 17 * WS_K; }
+static constexpr size_t ws_wgrad32_lds_bytes(bool recompute = false) {
+  return sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS + (recompute ? 2 * WS_ROWS * WS_XLP : 0)) > sizeof(float) * 17 * WS_K
+             ? sizeof(float) * ((size_t)2 * 2 * WW32_IMG + 2 * WS_ROWS + (recompute ? 2 * WS_ROWS * WS_XLP : 0)) : sizeof(float) * 17 * WS_K;
+}
 
 template <int MODE>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
-  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3);          // PLAIN: a materialised dZ as the A image, B = H0 itself (ws_gemm.h)
+  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3 || MODE == 4), RECOMP = (MODE == 4);   // PLAIN: a materialised dZ as the A image, B = H0 itself; RECOMP: H0 rebuilt from the narrow input (ws_gemm.h)
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   float* img = ws_smem;                                             // [buf][{mask, G}][32][WW32_P]   (PLAIN: {dZ, H0})
   float* dqs = img + 2 * 2 * WW32_IMG;                              // [buf][32]
+  float* Xl = dqs + 2 * WS_ROWS;                                    // RECOMP: [buf][32][WS_XLP] narrow input rows (ones column at in0)
   __shared__ f32x4 mlut[16];                                        // 4 mask bits -> 4 floats (0.0 / 1.0)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 15, lq = lane >> 4;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
@@ -398,6 +498,58 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   float dqsum = 0.f;
   float sdq[4];
   unsigned int sm_word;
+  // ---- RECOMP: first-layer fragments (k = 16 t + 4 lq + e) of this wave's columns and the narrow-input staging (ws_fwd_kernel<., L0, ., ., F32>) ----
+  const float* __restrict__ X0g = RECOMP ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
+  f32x4 b0w[2][2];
+  if (RECOMP) {
+    const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
+    const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int n = ncol0 + 16 * cb + li;
+      const float bn = b0g[n];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 16 * t + 4 * lq + j;
+          const float w = W0g[(long)n * p.w0_sn + (long)(k < p.in0 ? k : p.in0 - 1) * p.w0_sk];
+          b0w[cb][t][j] = (k < p.in0 ? 1.f : 0.f) * w + (k == p.in0 ? 1.f : 0.f) * bn;
+        }
+    }
+  }
+  const int xe = RECOMP ? WS_ROWS * p.x0_pitch : 0;
+  int xr[2], xc[2];
+  float sx[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + WS_NT * i;
+    xr[i] = RECOMP ? e / (RECOMP ? p.x0_pitch : 1) : 0; xc[i] = RECOMP ? e - xr[i] * p.x0_pitch : 0;
+    if (RECOMP && e >= xe) { xr[i] = 0; xc[i] = 32; }               // surplus threads: pad column 32 (rows are consumed as 32 columns of the 36-float pitch)
+  }
+  auto loadX = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }
+  };
+  auto storeX = [&](int xbuf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Xl[(xbuf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = (xc[i] == p.in0) ? 1.0f : sx[i];
+  };
+  f32x4 fx32[2];
+  auto prod_x = [&](int xbuf, int s) __attribute__((always_inline)) {
+    const float* xrow = Xl + (xbuf * WS_ROWS + 16 * s + li) * WS_XLP + 4 * lq;
+    fx32[0] = *(const f32x4*)xrow; fx32[1] = *(const f32x4*)(xrow + 16);
+  };
+  auto prod_block = [&](int buf, int s, int cb) __attribute__((always_inline)) {
+    float* gi = img + (long)buf * 2 * WW32_IMG + WW32_IMG;
+    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v = __builtin_amdgcn_mfma_f32_16x16x4f32(b0w[cb][t][e], fx32[t][e], v, 0, 0, 0);
+    orl_relu_mask4(v);
+    *(f32x4*)(gi + (16 * s + li) * WW32_P + ncol0 + 16 * cb + 4 * lq) = v;      // the lane holds C[m = 16 s + li][n = ncol0 + 16 cb + 4 lq ..]
+  };
   // (uniform part of every global address on the scalar ALU, per-thread part computed once: see ws_wgrad_kernel)
   const unsigned int vo_h0 = (unsigned int)((tid >> 6) * p.h0_pitch + 4 * (tid & 63));
   const unsigned int vo_h1 = (TAILS || PLAIN) ? (unsigned int)((tid >> 6) * h1_pitch + 4 * (tid & 63)) : 0u;
@@ -405,7 +557,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   const unsigned int vo_ab = (unsigned int)((tid >> 4) * p.ab_g + ((tid & 15) >> 1));
   auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
     const long row0 = (long)g * WS_ROWS + 8 * i;
-    s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
+    if (!RECOMP) s0[i] = *(const f32x4*)&(H0g + row0 * p.h0_pitch)[vo_h0];
     if (TAILS || PLAIN) s1[i] = *(const f32x4*)&(H1g + row0 * h1_pitch)[vo_h1];
     if (!PLAIN) sdq[i] = (dqg + row0 * p.dq_sm)[vo_dq];
   };
@@ -429,7 +581,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
     float* gi = img + (long)buf * 2 * WW32_IMG + WW32_IMG;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
     if (PLAIN) {
-      *(f32x4*)(gi + r * WW32_P + 4 * kq) = s0[i];
+      if (!RECOMP) *(f32x4*)(gi + r * WW32_P + 4 * kq) = s0[i];
       *(f32x4*)(gi - WW32_IMG + r * WW32_P + 4 * kq) = s1[i];          // the A image: dZ
       return;
     }
@@ -450,8 +602,22 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   };
 
   if (threadIdx.x < 16) mlut[threadIdx.x] = (f32x4){(float)(threadIdx.x & 1u), (float)((threadIdx.x >> 1) & 1u), (float)((threadIdx.x >> 2) & 1u), (float)(threadIdx.x >> 3)};
+  if (RECOMP) for (int e = tid; e < 2 * WS_ROWS * WS_XLP; e += WS_NT) Xl[e] = 0.f;      // columns >= x0_pitch stay zero
   __syncthreads();
   const int g0 = blockIdx.x, gs = gridDim.x;
+  if (RECOMP && g0 < p.groups) {                                    // (Xl[j & 1] holds the rows of iteration j: see ws_wgrad_kernel)
+    loadX(g0);
+    storeX(0);
+    if (g0 + gs < p.groups) loadX(g0 + gs);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      prod_x(0, s);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) prod_block(0, s, cb);
+    }
+    if (g0 + gs < p.groups) storeX(1);
+  }
   if (g0 < p.groups) {
     load_group(g0);
     store_group(0);
@@ -499,6 +665,14 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
         if (more) store_piece(buf ^ 1, kp);
         if (more2) load_piece(g + 2 * gs, kp);
       }
+      if (RECOMP) {
+        if (kp == 0 && more2) loadX(g + 2 * gs);
+        if (kp >= 4 && more) {
+          if (!(kp & 1)) prod_x(buf ^ 1, (kp - 4) >> 1);
+          prod_block(buf ^ 1, (kp - 4) >> 1, kp & 1);
+        }
+        if (kp == 7 && more2) storeX(buf);
+      }
       if (kp == 5) {
         if (more) store_mask(buf ^ 1);
         if (more2) load_mask(g + 2 * gs);
@@ -509,7 +683,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad32_kernel(const WsWgradP p) {
   int g = g0, it = 0;
   for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
-  ww_finish<MODE>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0);
+  ww_finish<(MODE == 4 ? 3 : MODE)>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0);
 }
 
 hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
@@ -523,10 +697,17 @@ hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes(true));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes(true, true));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes(true));
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 1, nz), block(WS_NT);
+  if (p.dZ && p.X0) {                              // ... with the layer's input activation recomputed from the net's narrow input
+    if (p.f32) hipLaunchKernelGGL(ws_wgrad32_kernel<4>, grid, block, ws_wgrad32_lds_bytes(true), st, p);
+    else hipLaunchKernelGGL(ws_wgrad_kernel<4>, grid, block, ws_wgrad_lds_bytes(true, true), st, p);
+    return hipGetLastError();
+  }
   if (p.dZ) {                                      // plain (materialised) gradient: a hidden layer below the top one
     if (p.f32) hipLaunchKernelGGL(ws_wgrad32_kernel<3>, grid, block, ws_wgrad32_lds_bytes(), st, p);
     else hipLaunchKernelGGL(ws_wgrad_kernel<3>, grid, block, ws_wgrad_lds_bytes(true), st, p);

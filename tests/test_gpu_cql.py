@@ -377,6 +377,31 @@ def test_three_layer_plain_weight_stationary_kernels_match_tiled_kernels(monkeyp
         enga.close(); engb.close()
 
 
+@pytest.mark.parametrize("precision", [1, 0])
+def test_three_layer_recomputed_first_activation_matches_the_stored_one(monkeypatch, precision):
+    """[256,256,256] critics, 8 runs: with ORL_WS_RECOMPUTE_H0=1 the forward does not store the first hidden activation and the middle layer's
+    weight gradient rebuilds it per row group from the 24-column input with the forward's own instruction sequence (ws_wgrad_kernel<4> /
+    ws_wgrad32_kernel<4>; an experiment that measured slower and is off by default, engine.h).  The rebuilt values are bit-identical to the
+    stored ones, so losses AND updated parameters must be bit-identical to the default engine's."""
+    case = "cql_halfcheetah_h3"
+    R = 8
+    enga, cfg, st, batches, noises = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.setenv("ORL_WS_RECOMPUTE_H0", "1")
+    engb, _, _, _, _ = make_engine(case, n_runs=R, precision=precision)
+    monkeypatch.delenv("ORL_WS_RECOMPUTE_H0")
+    try:
+        for k, (b, n) in enumerate(zip(batches[:3], noises[:3])):
+            ma = enga.step(lead(b, R), lead(noise_list(n), R))
+            mb = engb.step(lead(b, R), lead(noise_list(n), R))
+            assert np.array_equal(ma, mb), (k, ma[0], mb[0])
+        for nm in ("critic1", "critic2"):
+            a, b1 = enga.get_net(R - 1, NETS[nm]), engb.get_net(R - 1, NETS[nm])
+            for pn in a:
+                assert np.array_equal(a[pn], b1[pn]), (nm, pn)
+    finally:
+        enga.close(); engb.close()
+
+
 @pytest.mark.parametrize("case", list(synth.CQL_EXTRA_CASES) + ["cql_halfcheetah_h3"])
 @pytest.mark.parametrize("precision", [0, 1])
 def test_cql_many_runs_kernel_selection_corners(case, precision):
