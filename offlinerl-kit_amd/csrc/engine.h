@@ -165,6 +165,7 @@ struct Engine {
   long ws_wgrad_min_rows = 15000;   // batched rows from which the output-stationary wgrad kernel is used (ORL_WS_WGRAD_MIN overrides; round 4: 40 000 -> 15 000, the 15 872 critic rows of ONE run: 1 run +4.3 %, 2 runs +1.7 %, fp32 +7.4 % / +0.7 %)
   int ws_wgrad_min_m = 1024;        // ... and rows PER NET: a 256-row net is 8 row groups behind a 256 KB slab write -- the tiled wgrad is faster there
                                     // (IQL / TD3+BC at 128 runs: +1.2 %; ORL_WS_WGRAD_MIN_M overrides)
+  int ws_wgrad_slab_cap = 128;      // slabs (= workgroups per net) of the output-stationary wgrad: Adam reads every one of them (ORL_WS_WGRAD_SLABS)
   bool ws_wgrad_rows_ok(int M, int nz) const { return (long)M * nz >= ws_wgrad_min_rows && M >= ws_wgrad_min_m; }
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
   bool use_ws32 = true;        // ... and their exact-fp32 variants at precision 0 (ORL_WS32=0: tiled fp32 kernels only)

@@ -779,7 +779,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
+      const int per_z = ws_dgrad_blocks(M, nz, ws_wgrad_slab_cap, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
       prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
                  nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
@@ -904,6 +904,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
     if (fuse_small && jobs && jobs_done && njobs >= 1 && njobs <= 3 && nr.nz1 == 1 && l.out_dim == 2 * ad && ad <= 8 && out.pitch == l.out_dim) {
       w.njobs = njobs; w.A = ad;
       for (int i = 0; i < njobs; ++i) w.job[i] = jobs[i];
+      if (!small_fwd_supported(w)) w.njobs = 0;      // (e.g. more than 16 repeated actions per row: the pass stays one launch, the sampling its own)
     }
     if (small_fwd_supported(w)) {
       const int nz = R * nr.nz1;
@@ -1172,6 +1173,7 @@ int Engine::init(const orl_config& c) {
   ORL_HIP(hipStreamSynchronize(stream));
   { const char* f = getenv("ORL_WS_WGRAD_MIN"); if (f && atol(f) > 0) ws_wgrad_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_WGRAD_MIN_M"); if (f && atoi(f) > 0) ws_wgrad_min_m = atoi(f); }
+  { const char* f = getenv("ORL_WS_WGRAD_SLABS"); if (f && atoi(f) > 0) ws_wgrad_slab_cap = std::min(atoi(f), max_slab); }
   { const char* f = getenv("ORL_WS_DGRAD_PLAIN_MIN"); if (f && atol(f) > 0) ws_dgrad_plain_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_FWD_MIN"); if (f && atol(f) > 0) ws_fwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
