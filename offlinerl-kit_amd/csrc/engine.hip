@@ -479,6 +479,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       if (fused0) bits_live.insert(X.bits);
       if (w.x0_discard) vals_dead.insert(X.p);
       else if (fused0) vals_dead.erase(X.p);
+      if (M >= 1024 && !fwd_only) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 64;      // (lab builds: the critic pass)
       hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
@@ -782,6 +783,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       const int per_z = ws_dgrad_blocks(M, nz, ws_wgrad_slab_cap, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
       prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
                  nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
+      w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 72;
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
@@ -1149,7 +1151,7 @@ int Engine::init(const orl_config& c) {
   gscale_buf = raw_alloc(sizeof(float) * (size_t)GSCALE_SLOTS * R);
   gscale_inv_b = raw_alloc(sizeof(float) * (size_t)R);
   cql_ticket = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
-  aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 128));
+  aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 192));
   health = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
   health_host.assign(R, 0u);
   if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health || !aloss_part) return fail("hipMalloc state");
@@ -1200,7 +1202,7 @@ int Engine::init(const orl_config& c) {
     case ORL_ALGO_MCQ: rc = mcq_build(); break;
   }
   if (rc) return rc;
-  { Mat lc; lc.p = aloss_part + (long)R * SB_MAXGROUPS * 2; lc.pitch = 128; taps["lab_clk"] = {lc, 1, 128}; }      // shader-clock stamps of lab builds (small_bwd.hip)
+  { Mat lc; lc.p = aloss_part + (long)R * SB_MAXGROUPS * 2; lc.pitch = 192; taps["lab_clk"] = {lc, 1, 192}; }      // shader-clock stamps of lab builds (small_bwd.hip)
   for (auto& ns : noise_slots) taps[ns.name] = {W(ns.name), ns.rows, ns.cols ? ns.cols : ad};      // the noise arrays of the last step
   nm = (int)metric_names.size();
   if (nm > ORL_MAX_METRICS) return fail("too many metrics");

@@ -29,6 +29,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   float* __restrict__ Y0g = L0 ? const_cast<float*>(Xg) : nullptr;       // L0: h0 is written where the plain kernel reads it
   const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
 
+  WS_STAMP(0);
   // ---- resident B fragments: lane (li, lq) supplies W[n = ncol0 + 16 cb + li][k = 32 ks + 8 lq .. +7] ----
   // F32: lane (li, lq) supplies W[n][k = 16 t + 4 lq .. + 3], t = 0..15 (element e of the float4 = MFMA k step e of block t)
   hx8 bh[WS_CB][F32 ? 1 : 8], bl[WS_CB][F32 ? 1 : 8];
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) ws_split8(raw[cb][ks][0] * ORL_WSCALE, raw[cb][ks][1] * ORL_WSCALE, bh[cb][ks], bl[cb][ks]);
   }
+  WS_STAMP(1);
   // L0: first-layer fragments of the same columns, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond
   hx8 b0h[WS_CB], b0l[WS_CB];
   f32x4 b0w[WS_CB][2];                              // F32: k = 16 t + 4 lq + e
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
   const int g0 = blockIdx.x, gs = gridDim.x;
   if (g0 >= p.groups) return;
+  WS_STAMP(2);
   if (L0) {
     for (int e = tid; e < 2 * WS_ROWS * WS_XLP; e += WS_NT) Xl[e] = 0.f;   // columns >= x0_pitch stay zero
     loadX(g0);
@@ -444,7 +447,9 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
       for (int cb = 0; cb < WS_CB; ++cb) pacc[s][cb] = acc[s][cb];
   };
   int g = g0, it = 0;
+  WS_STAMP(3);
   iteration(g, it, st0, true, false);
+  WS_STAMP(4);
   g += gs; ++it;
   while (g + 3 * gs < p.groups) {
     iteration(g, it, st0, false, true);
@@ -454,10 +459,12 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     iteration(g, it, st0, false, false);
     g += gs; ++it;
   }
+  WS_STAMP(5);
   // drain: the last group's epilogue
   epilogue(pacc, g - gs, (it - 1) & 1);
   __syncthreads();
   finish(g - gs, (it - 1) & 1);
+  WS_STAMP(6);
 }
 
 template <bool F32>

@@ -28,6 +28,12 @@
 
 namespace orl {
 
+#ifdef SB_LAB_CLOCK
+#define WS_STAMP(i) do { if (p.lab_clk && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.z == 0) p.lab_clk[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WS_STAMP(i) do { } while (0)
+#endif
+
 struct WsFwdP {
   const float* X; long x_s0, x_s1; int x_pitch;        // input activations [z][M][K] fp32, K == 256
   const float* W; long w_s0, w_s1;                      // weights of problem z; element (n, k) at W[n * w_sn + k * w_sk]:
@@ -38,6 +44,7 @@ struct WsFwdP {
   const float* tw; long tw_s0, tw_s1;                   // fused tail: q[m] = Y[m] . tw + tb  (null = off)
   const float* tb; long tb_s0, tb_s1;
   float* tq; long tq_s0, tq_s1, tq_sm;
+  unsigned long long* lab_clk;                          // lab builds (-DSB_LAB_CLOCK): shader-clock stamps of workgroup (0, 0, 0)
   int M, nz1, groups;                                   // groups = ceil(M / WS_ROWS)
   // fused first layer (template L0): X is then PRODUCED here as relu(X0 W0^T + b0) from the narrow input rows X0 (in0 + 1 <= 32 columns
   // incl. the bias as a ones column), stored to `X` for the backward pass, and handed to the second layer through LDS only
@@ -215,6 +222,7 @@ struct WsWgradP {
   const float* X0; long x0_s0, x0_s1; int x0_pitch, in0;
   const float* W0; long w0_s0, w0_s1, w0_sn, w0_sk;
   const float* b0; long b0_s0, b0_s1;
+  unsigned long long* lab_clk;                                 // lab builds (-DSB_LAB_CLOCK): shader-clock stamps of workgroup (0, 0, 0)
   int M, nz1, groups;
   int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of the split 16-bit planes
   const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq / dZ, one float per run (z0); null = 1

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   // split precision: G = (dq * gs) (.) h0 (PLAIN: dZ * gs) with the run's dynamic power-of-two gradient scale gs, divided out of the slab in ww_finish
   const float gsc = p.gscale ? p.gscale[z0] : 1.f;
 
+  WS_STAMP(0);
   f32x4 acc[16][2], accb[2];
 #pragma unroll
   for (int kb = 0; kb < 16; ++kb)
@@ -339,6 +340,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   __syncthreads();
 
   const int g0 = blockIdx.x, gs = gridDim.x;
+  WS_STAMP(1);
   // RECOMP: the narrow rows of iteration j live in Xl[j & 1]; iteration `it` produces h0 of iteration it + 1 into the other image and stages
   // the rows of iteration it + 2 where iteration it - 1 read its own
   if (RECOMP && g0 < p.groups) {
@@ -450,10 +452,13 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     __syncthreads();
   };
   int g = g0, it = 0;
+  WS_STAMP(2);
   for (; MODE != 1 && g + 2 * gs < p.groups; g += gs, ++it) iteration(g, it, true);    // (the h1-streaming variant measured slower that way)
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
+  WS_STAMP(3);
 
   ww_finish<(MODE == 4 ? 3 : MODE)>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
+  WS_STAMP(4);
 }
 
 // ---- exact-fp32 flavour (precision 0): the same output-stationary structure on v_mfma_f32_16x16x4_f32 ----

@@ -25,3 +25,6 @@ for _ in range(3):
         f = allc[16 + 12 * k: 16 + 12 * k + 8]
         n = int((f > 0).sum())
         print("   small_fwd %-24s total %6d | %s" % (name, f[n - 1] - f[0], " ".join("%d:%d" % (i + 1, x) for i, x in enumerate(np.diff(f[:n])))))
+    for off, name, n in ((64, "ws_fwd critic pass (start | weights | L0 frags | prologue | first group | loop | drain)", 7), (72, "ws_wgrad critic (start | setup | prologue | loop | finish)", 5)):
+        f = allc[off:off + n]
+        print("   %-90s total %6d | %s" % (name, f[-1] - f[0], " ".join("%d" % x for x in np.diff(f))))
