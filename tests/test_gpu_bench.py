@@ -41,3 +41,53 @@ def test_bench_prints_one_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in cpu, k
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+
+
+def test_two_engines_in_the_one_round_geometry_match_their_solo_runs():
+    """The combination bench.py's default actually runs: TWO engines per GPU, each created with `ws_one_round = 1`
+    (weight-stationary launches on CUs / nets workgroups per net), each on its own HIP stream and host thread, sampling the same HBM buffer
+    concurrently.  Engines are independent, so what an engine computes must not depend on what runs beside it: 20 device-sampled steps of
+    both engines side by side give bit-identical metrics and parameters to the same two engines (same seeds) stepped one after the other."""
+    import threading
+
+    import numpy as np
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "offlinerl-kit_amd")]
+    import bench_workloads as bw
+    from offlinerlkit import _engine
+    R = 24                                            # 48 batched critics: 5 workgroups per net in the one-round decomposition
+    ds = bw.make_dataset(0, 100_000, 17, 6)
+    buf = _engine.DeviceBuffer(17, 6, 0)
+    buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
+
+    def make():
+        es = [bw.make_engine("cql", R, 1, 0, 40 + e, ws_one_round=1) for e in range(2)]
+        for g in es:
+            g.attach_buffer(buf)
+        return es
+
+    side = make()
+    out = [None, None]
+
+    def work(i):
+        out[i] = side[i].learn_n(20)[0]
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    solo = make()
+    ref = [g.learn_n(20)[0] for g in solo]
+    try:
+        for i in range(2):
+            assert np.isfinite(out[i]).all()
+            assert np.array_equal(out[i], ref[i]), (i, np.abs(out[i] - ref[i]).max())
+            for r in (0, R - 1):
+                for net in (0, 1, 2):
+                    a, b = side[i].get_net(r, net), solo[i].get_net(r, net)
+                    for k in a:
+                        assert np.array_equal(a[k], b[k]), (i, r, net, k)
+        assert not np.array_equal(out[0], out[1])     # different seeds: different trainings
+    finally:
+        for g in side + solo:
+            g.close()
+        buf.close()
