@@ -18,8 +18,12 @@ The timed block of K steps (barrier + synchronize on both sides, max over ranks)
 >= 2 s, --min-reps / --min-seconds); `value` is the median block, every block is listed in `reps`.
 Side records of the same run (rank 0, N = 1 only): `value_fp32` / `fp32` (exact-fp32 MFMA, same workload), `target`
 (both over the north_star's 50k), `by_runs` (runs per GPU 1 .. 192), `other_configs` (TD3BC, IQL = BASELINE configs[2], EDAC =
-configs[3]; 128 runs each), `api` (a fused MFPolicyTrainer epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer),
-`roofline` (+ `traffic_source`), `cpu_baseline`.  `--rccl-check` opens a world-size-1 nccl group and runs the path's collectives
+configs[3]; 128 runs each), `api` (a fused MFPolicyTrainer epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer with the split
+products selected), `api_default` (the same epoch with NO engine options set: what a user of the reference's API gets untouched -- one run,
+exact fp32), `config5_per_gpu` (one engine x 8 seeds on the halfcheetah and the hopper shape: what each rank of BASELINE configs[4] runs),
+`roofline` (+ `traffic_source`), `cpu_baseline` (the numpy port on 1 / 16 / 64 threads, each labelled with the threads it used).
+`--preset config5` (BASELINE configs[4]: 8 tasks x 8 seeds): one engine x 8 runs per GPU, rank r on D4RL task r % 8 with that task's
+observation / action widths and dataset size (`config.tasks_by_rank`).  `--rccl-check` opens a world-size-1 nccl group and runs the path's collectives
 on device tensors (tests/test_gpu_rccl.py).  Workload construction shared with the tools lives in bench_workloads.py.
 """
 from __future__ import annotations
