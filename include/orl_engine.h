@@ -28,6 +28,14 @@
  *     for the bf16-plane variant build).  In this mode hidden activations
  *     and inputs must stay below 65504 in magnitude (fp16 range) and weights
  *     below 1023 (they enter the products times 2^6): see orl_health.
+ *     2 = three fp16 planes per operand (hi + mid + lo = 33 significand bits:
+ *     an fp32 operand is represented exactly) and the six products down to
+ *     2^-33 with fp32 accumulation -- the arithmetic class of the fp32 MFMA at
+ *     more than its rate -- in the launches that carry a many-row critic's
+ *     forward / top-layer dgrad / top-layer wgrad (two-hidden-layer
+ *     single-output nets from ~15 000 batched rows: CQL's critics); every other
+ *     launch runs the precision-0 kernels.  The fp16 operand range of
+ *     precision 1 applies to those launches.
  *   - orl_step / orl_learn_n additionally return ORL_RC_UNHEALTHY (1) when the
  *     step(s) ran but a run's health flag is raised (non-finite loss or
  *     gradient, an operand beyond the split-precision range): results are
@@ -101,7 +109,7 @@ typedef struct orl_config {
   int32_t batch_size;
   int32_t n_runs;    /* independent runs carried by this engine (>=1) */
   int32_t device;    /* HIP device ordinal */
-  int32_t precision; /* 0 fp32 MFMA, 1 split-bf16 */
+  int32_t precision; /* 0 fp32 MFMA; 1 split-fp16 MFMA (hi + lo planes); 2 three fp16 planes (exact fp32 operands, six products) in the many-row critic launches, fp32 MFMA elsewhere */
   uint64_t seed;     /* device Philox seed for orl_learn_n */
   float gamma, tau;
   float actor_lr, critic_lr, alpha_lr;

@@ -170,7 +170,16 @@ struct Engine {
   bool use_ws = true;          // weight-stationary kernels (csrc/ws_gemm.h); ORL_WS=0 keeps everything on the tiled kernels (tests)
   bool use_ws32 = true;        // ... and their exact-fp32 variants at precision 0 (ORL_WS32=0: tiled fp32 kernels only)
   WsGeom ws_geo;               // workgroups per net / CUs per launch of the weight-stationary kernels (orl_config::ws_one_round, ws_cus)
-  bool ws_precision_ok() const { return use_ws && (cfg.precision == 1 || (cfg.precision == 0 && use_ws32)); }
+  bool ws_precision_ok() const { return use_ws && (cfg.precision == 1 || use_ws32); }
+  // precision 2 = fp32-class arithmetic at more than the fp32 MFMA rate: the launches that have a three-plane flavour (the many-row critic's
+  // fused forward, its top-layer dgrad + layer-0 wgrad, its top-layer wgrad: ws_fwd3 / ws_dgrad3 / ws_wgrad_kernel<5>) multiply three fp16
+  // planes per operand (six resp. three products), every other launch is the exact-fp32 kernel of precision 0.  The gradient scales and the
+  // fp16 range watch of precision 1 apply (the planes are fp16); fp32 kernels ignore the scales.
+  bool split_scales() const { return cfg.precision >= 1; }
+  int mm_prec() const { return cfg.precision == 1 ? 1 : 0; }       // precision of a launch without a three-plane flavour
+  int p3_mask = 7;                                                  // ORL_P3: bit 0 forward, 1 dgrad, 2 wgrad (lab: single kernels against their fp32 twins)
+  bool p3(int bit) const { return cfg.precision == 2 && (p3_mask & bit); }
+  float* ws_dump = nullptr;                                         // precision 2: scratch lines of ws_fwd3_kernel (WS_DUMP_SLOTS x WS_N floats)
   // split precision: per-run dynamic power-of-two scale of the gradient matrices of the backward pass being enqueued (k_grad_scale);
   // one slot per backward pass of a step, fixed order, so a captured graph replays with the same slots
   float* gscale_buf = nullptr;       // [GSCALE_SLOTS][R]

@@ -280,14 +280,14 @@ void Engine::prof_end() {
 }
 
 float* Engine::gscale_slot() {
-  if (cfg.precision != 1) return nullptr;
+  if (!split_scales()) return nullptr;
   if (gscale_next >= GSCALE_SLOTS) { fail("grad_scale: out of slots"); return nullptr; }
   return gscale_buf + (long)(gscale_next++) * R;
 }
 
 // split precision: choose the dynamic scale of a backward pass from its seed (kernels.h: k_grad_scale); null at precision 0
 const float* Engine::grad_scale(const Mat& seed, int rows, int cols, int nets, const char* tag) {
-  if (cfg.precision != 1) return nullptr;
+  if (!split_scales()) return nullptr;
   if (gscale_next >= GSCALE_SLOTS) { fail("grad_scale: out of slots"); return nullptr; }
   float* out = gscale_buf + (long)(gscale_next++) * R;
   GradScaleP g;
@@ -299,7 +299,7 @@ const float* Engine::grad_scale(const Mat& seed, int rows, int cols, int nets, c
 }
 
 void Engine::watch_range(const Mat& m, int rows, int cols, int nets, const char* what) {
-  if (cfg.precision != 1 || !m.p) return;
+  if (!split_scales() || !m.p) return;
   RangeWatch w{m, rows, cols, nets, what ? what : ""};
   range_watch[m.p] = w;
 }
@@ -307,7 +307,7 @@ void Engine::watch_range(const Mat& m, int rows, int cols, int nets, const char*
 // every matrix the last enqueued step feeds to the split-precision MFMAs at operand scale 1 (dead ones -- never stored by the forward pass --
 // skipped), then the parameters of every net (operand scale ORL_WSCALE)
 int Engine::range_scan() {
-  if (cfg.precision != 1) return 0;
+  if (!split_scales()) return 0;
   const float lim = 65504.0f;
   for (auto& kv : range_watch) {
     const RangeWatch& w = kv.second;
@@ -339,7 +339,7 @@ int Engine::health_update(const float* metrics, long steps_done, unsigned int* a
     health_host[r] |= f;
   }
   steps_since_scan += steps_done > 0 ? steps_done : 0;
-  if (cfg.precision == 1 && (fresh || steps_done < 0 || steps_since_scan >= RANGE_SCAN_EVERY)) {
+  if (split_scales() && (fresh || steps_done < 0 || steps_since_scan >= RANGE_SCAN_EVERY)) {
     steps_since_scan = 0;
     if (range_scan()) return -1;
     ORL_HIP(hipStreamSynchronize(stream));
@@ -383,7 +383,7 @@ static int run_gemm(Engine* e, int cfg, const GemmP& p, int nz, const char* tag,
   double bytes_adj = bytes;
   if (EPI == E_MASK && p.w0_out) bytes_adj += 4.0 * nz * ((double)p.M * p.w0_xsr - (p.C ? 0.0 : (double)p.M * p.N));
   e->prof_begin(tag, flops + (EPI == E_MASK && p.w0_out ? 2.0 * p.M * (double)p.N * (p.w0_in + 1) * nz : 0.0), bytes_adj);
-  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar, e->cfg.precision);
+  hipError_t err = launch_gemm<PA, PB, EPI>(cfg, p, nz, e->stream, a_kpad, e->force_scalar, e->mm_prec());
   e->prof_end();
   if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
   return 0;
@@ -444,7 +444,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     w.bias = nr.base + l.b_off[layer]; w.b_s0 = nr.rs; w.b_s1 = l.b_ms[layer];
     w.Y = Y.p; w.y_s0 = Y.rs; w.y_s1 = Y.cs; w.y_pitch = Y.pitch;
     w.mb = Y.bits; w.mb_s0 = Y.brs; w.mb_s1 = Y.bcs; w.mb_g = Y.bg;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0;
     const bool want_tail = tail_out && tail_fused && layer == l.L - 1 && l.out_dim == 1;
     if (want_tail) {
       w.tw = nr.base + l.w_off[l.L]; w.tw_s0 = nr.rs; w.tw_s1 = l.w_ms[l.L];
@@ -472,17 +472,37 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       fuse_X0 = nullptr;
     }
     if (ws_ok) {
+      // precision 2: the fused first + second layer + tail forward of a many-row single-output net has a three-plane flavour (ws_fwd3.hip);
+      // its two column halves leave two tail partial sums
+      bool fwd3 = false;
+      if (p3(1) && fused0 && want_tail && !w.Y && !w.x0_discard && !l.ens && ws_dump && ws.count("tq_scratch")) {
+        const Mat& sc = ws.at("tq_scratch");
+        if ((long)M <= sc.cs && nr.nz1 <= tq_scratch_nets) {
+          w.np3 = 1; w.tq2 = sc.p; w.tq2_s0 = sc.rs; w.tq2_s1 = sc.cs; w.dump = ws_dump;
+          fwd3 = ws_fwd3_supported(w, in, out);
+          if (!fwd3) { w.np3 = 0; w.tq2 = nullptr; w.dump = nullptr; }
+        }
+      }
       const double f0 = fused0 ? 2.0 * M * (double)in * (w.in0 + 1) * nz : 0.0;
-      prof_begin(tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
+      prof_begin(fwd3 ? (std::string(tag) + "@p3").c_str() : tag, f0 + 2.0 * M * (double)out * (in + (want_tail ? 1 : 0)) * nz,
                  4.0 * nz * ((fused0 ? (double)M * w.x0_pitch : 0.0) + (w.x0_discard ? (double)M * in / 32 : (double)M * in) + (double)out * in +
                              (elide ? (double)M * out / 32 : (double)M * out)));
       if (fused0) bits_live.insert(X.bits);
       if (w.x0_discard) vals_dead.insert(X.p);
       else if (fused0) vals_dead.erase(X.p);
       if (M >= 1024 && !fwd_only) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 64;      // (lab builds: the critic pass)
-      hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
+      hipError_t err = fwd3 ? launch_ws_fwd3(w, nz, ws_blocks_per_problem(M / WS_ROWS, 2 * nz, 10, 1 << 20, ws_geo), stream) : launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
+      if (fwd3) {
+        TailAddP t;
+        t.out = w.tq; t.o_s0 = w.tq_s0; t.o_s1 = w.tq_s1; t.o_sm = w.tq_sm;
+        t.part = w.tq2; t.p_s0 = w.tq2_s0; t.p_s1 = w.tq2_s1; t.p_ts = M; t.nparts = 1; t.M = M; t.nz1 = nr.nz1;
+        prof_begin((std::string(tag) + ".tail_add").c_str(), 0);
+        hipLaunchKernelGGL(k_tail_add, dim3((M + 255) / 256, nz), dim3(256), 0, stream, t);
+        prof_end();
+        if (hipGetLastError() != hipSuccess) return fail("tail_add launch");
+      }
       bits_live.insert(Y.bits);
       if (elide) vals_dead.insert(Y.p);
       if (tail_fused) *tail_fused = want_tail;
@@ -573,12 +593,13 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
     w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0); w.o_sc = 1;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
-      prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
+      const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes, two workgroups (column halves) per slab
+      const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, max_slab, ws_geo);
+      prof_begin(d3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
                  nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (w0_X->pitch + 1) + 4.0 * per_z * in * (l.layer_in(0) + 1)));
-      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      hipError_t err = d3 ? launch_ws_dgrad3_w0(w, nz, per_z, stream) : launch_ws_dgrad_w0(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
       *w0_slabs = per_z;
@@ -597,7 +618,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, 1 << 20, ws_geo);
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
@@ -623,7 +644,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     // nn.Linear keeps (out, in)-major weights, EnsembleLinear (in, out)-major ones: the same holds for the gradient slabs
     if (l.ens) { w.w_sn = out; w.w_sk = 1; w.o_sr = 1; w.o_sc = l.layer_out(0); }
     else { w.w_sn = 1; w.w_sk = in; w.o_sr = l.layer_in(0); w.o_sc = 1; }
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
       prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
@@ -659,7 +680,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.Y = dX.p; w.y_s0 = dX.rs; w.y_s1 = dX.cs; w.y_pitch = dX.pitch;
     w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_fwd_supported(w, out, in)) {
       prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
       hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
@@ -679,7 +700,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
         const double bytes = nz * (4.0 * q.N * q.K + q.M * (double)q.K / 8 + (q.C ? 4.0 * q.M * q.N : 0.0) +
                                    (q.aux_bits ? q.M * (double)q.N / 8 : 4.0 * q.M * q.N) + (q.w0_out ? 4.0 * q.M * q.w0_xsr : 0.0));
         prof_begin(tag, flops, bytes);
-        hipError_t err = launch_gemm_rank1_bits<E_MASK>(tcfg, q, nz, stream, this->cfg.precision);
+        hipError_t err = launch_gemm_rank1_bits<E_MASK>(tcfg, q, nz, stream, this->mm_prec());
         prof_end();
         if (err != hipSuccess) return fail(std::string("gemm launch ") + tag + ": " + hipGetErrorString(err));
         return 0;
@@ -778,10 +799,11 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       w.b1 = nr.base + l.b_off[layer]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[layer];
     } else { w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch; }
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.np3 = p3(4) && derived;                                        // precision 2: three planes of G = dq (.) h0 (ws_wgrad_kernel<5>)
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, ws_wgrad_slab_cap, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
-      prof_begin(tag, 2.0 * M * (double)in * (out + 2) * nz,
+      prof_begin(w.np3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * (out + 2) * nz,
                  nz * ((derived ? M * (double)out / 8 : 4.0 * M * (double)out) + 4.0 * M * (in + 1) + 4.0 * per_z * out * (in + 2)));
       w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 72;
       hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
@@ -807,7 +829,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     }
     w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->cfg.precision == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);
       prof_begin(tag, 2.0 * M * (double)in * (out + 1 + (x_dead ? w.in0 + 1 : 0)) * nz,
@@ -902,7 +924,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
       w.H1 = hs[1].p; w.h1_s0 = hs[1].rs; w.h1_s1 = hs[1].cs;
     }
     w.OUT = out.p; w.o_s0 = out.rs; w.o_s1 = out.cs; w.o_pitch = out.pitch; w.out_dim = l.out_dim;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = mm_prec() == 0;
     if (fuse_small && jobs && jobs_done && njobs >= 1 && njobs <= 3 && nr.nz1 == 1 && l.out_dim == 2 * ad && ad <= 8 && out.pitch == l.out_dim) {
       w.njobs = njobs; w.A = ad;
       for (int i = 0; i < njobs; ++i) w.job[i] = jobs[i];
@@ -952,7 +974,7 @@ int Engine::mlp_qgrad(const Mat& X, int M, const NetRef& nr, const Mat& q, const
   w.bt = nr.base + l.b_off[2]; w.bt_s0 = nr.rs; w.bt_s1 = l.b_ms[2];
   w.OUT = q.p; w.o_s0 = q.rs; w.o_s1 = q.cs; w.o_pitch = q.pitch; w.out_dim = 1;
   w.G = G.p; w.g_s0 = G.rs; w.g_s1 = G.cs; w.g_pitch = G.pitch; w.gc0 = gc0; w.gn = gn;
-  w.M = M; w.nz1 = nr.nz1; w.f32 = cfg.precision == 0;
+  w.M = M; w.nz1 = nr.nz1; w.f32 = mm_prec() == 0;
   if (!small_fwd_supported(w)) return 0;
   const int nz = R * nr.nz1;
   if (lab_slot < 4) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 16 + 12 * lab_slot++;
@@ -1021,7 +1043,7 @@ static int mlp_backward(Engine* e, const NetRef& nr, const Mat& X, const std::ve
   // split precision: every gradient matrix of this pass enters the MFMAs times one dynamic power-of-two scale per run, chosen from the seed
   struct ScaleScope { Engine* e; const float* prev; ~ScaleScope() { e->cur_gscale = prev; } } scope{e, e->cur_gscale};
   e->cur_gscale = gscale_given ? gscale_given : e->grad_scale(dTail, M, l.out_dim, nr.nz1, tag);
-  if (e->cfg.precision == 1 && !e->cur_gscale) return -1;
+  if (e->split_scales() && !e->cur_gscale) return -1;
   if (want_w) {
     for (int i = 0; i <= L; ++i) ks[i] = wgrad_ksplit(l.layer_out(i), l.layer_in(i), M, nz, e->ksplit_cap);
     if (!rank1 && e->linear_wgrad(DY::plain(dTail), hs[L - 1], M, nr, L, ks[L], 0, true, (t + ".wgrad_tail").c_str())) return -1;
@@ -1129,7 +1151,7 @@ int Engine::init(const orl_config& c) {
   if (c.device < 0 || c.device >= ndev) return fail("bad device ordinal");
   dev = c.device;
   ORL_HIP(hipSetDevice(dev));
-  if (c.precision != 0 && c.precision != 1) return fail("precision must be 0 (fp32 MFMA) or 1 (split-precision MFMA)");
+  if (c.precision < 0 || c.precision > 2) return fail("precision must be 0 (fp32 MFMA), 1 (split-precision MFMA: two fp16 planes) or 2 (three fp16 planes where a kernel has them, fp32 MFMA elsewhere)");
   if (c.actor_dropout != 0.f && (c.algo != ORL_ALGO_IQL || !(c.actor_dropout > 0.f && c.actor_dropout < 1.f)))
     return fail("actor_dropout: supported for IQL only (run_iql.py --dropout_rate), 0 < p < 1");
   if (build_layouts(c, lay, net_off, net_is_target, &P_train, &P_tgt)) return -1;
@@ -1154,6 +1176,10 @@ int Engine::init(const orl_config& c) {
   aloss_part = raw_alloc(sizeof(float) * ((size_t)R * SB_MAXGROUPS * 2 + 192));
   health = (unsigned int*)raw_alloc(sizeof(unsigned int) * (size_t)R);
   health_host.assign(R, 0u);
+  if (c.precision == 2) {
+    ws_dump = raw_alloc(sizeof(float) * (size_t)WS_DUMP_SLOTS * WS_N);
+    if (!ws_dump) return fail("hipMalloc scratch lines");
+  }
   if (!adam_m || !adam_v || !grads || !scalars || !hyper || !gstep || !gscale_buf || !gscale_inv_b || !cql_ticket || !health || !aloss_part) return fail("hipMalloc state");
   {
     std::vector<float> inv(R, orl_pow2_scale(1.0f / (float)c.batch_size));
@@ -1181,6 +1207,7 @@ int Engine::init(const orl_config& c) {
   { const char* f = getenv("ORL_SMALL_FWD"); if (f) small_fwd_on = atoi(f) != 0; }
   { const char* f = getenv("ORL_FUSE_SMALL"); if (f) fuse_small = atoi(f) != 0; }
   { const char* f = getenv("ORL_WS_RECOMPUTE_H0"); if (f) recompute_h0 = atoi(f) != 0; }
+  { const char* f = getenv("ORL_P3"); if (f) p3_mask = atoi(f); }
   { const char* f = getenv("ORL_SMALL_FWD_MAX"); if (f && atol(f) > 0) small_fwd_max_rows = atol(f); }
   { const char* f = getenv("ORL_WS_BWD_MIN"); if (f && atol(f) > 0) ws_bwd_min_rows = atol(f); }
   { const char* f = getenv("ORL_WS_KEEP_H1"); elide_top = !(f && atoi(f) != 0); }
@@ -1596,7 +1623,7 @@ int orl_engine_attach_buffer(orl_engine* h, orl_buffer* b) {
   if (!b) { h->e.buf = nullptr; h->e.drop_graphs(); return 0; }
   if (b->b.od != h->e.od || b->b.ad != h->e.ad) return fail("attach_buffer: obs/act dims differ from the engine's");
   if (b->b.dev != h->e.dev) return fail("attach_buffer: buffer lives on another device");
-  if (h->e.cfg.precision == 1 && b->b.obs) {
+  if (h->e.split_scales() && b->b.obs) {
     // split precision multiplies fp16 hi + lo planes: an observation or action component of 65504 or more is +-inf there.  The dataset is
     // checked once per load (a 40 us reduction over the HBM arrays), not per sampled batch.
     Buffer& bb = b->b;

@@ -102,6 +102,39 @@ __device__ __forceinline__ void orl_split4(const f32x4& v, hx4& h, hx4& l) {
 }
 #endif
 __device__ __forceinline__ void orl_split1(float x, hx_t& h, hx_t& l) { h = (hx_t)x; l = (hx_t)(x - (float)h); }
+// Three planes (precision 2): x = hi + mid + lo with hi = half(x), mid = half(x - hi), lo = half(x - hi - mid); both remainders are exact in
+// fp32, so the three fp16 planes carry 33 significand bits wherever the last plane stays on fp16's 2^-24 grid -- an fp32 operand is
+// represented exactly (the operand scales keep it there) and the six products hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi with fp32
+// accumulation drop only terms below 2^-33 of the product: the arithmetic class of v_mfma_f32_16x16x4_f32 at 2500 / 6 TFLOP/s.
+// 14 vector instructions for four values (8 for two planes).
+__device__ __forceinline__ void orl_split4x3(const f32x4& v, hx4& h, hx4& m, hx4& l) {
+  h = __builtin_convertvector(v, hx4);
+#if defined(ORL_SPLIT_BF16) || defined(ORL_SPLIT_NO_MIX)
+  const f32x4 r1 = v - __builtin_convertvector(h, f32x4);
+  m = __builtin_convertvector(r1, hx4);
+  l = __builtin_convertvector(r1 - __builtin_convertvector(m, f32x4), hx4);
+#else
+  const u32x2_t hb = *(const u32x2_t*)&h;
+  f32x4 r1, r2;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r1[0]) : "v"(hb[0]), "v"(v[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1[1]) : "v"(hb[0]), "v"(v[1]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r1[2]) : "v"(hb[1]), "v"(v[2]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1[3]) : "v"(hb[1]), "v"(v[3]));
+  m = __builtin_convertvector(r1, hx4);
+  const u32x2_t mb = *(const u32x2_t*)&m;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2[0]) : "v"(mb[0]), "v"(r1[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r2[1]) : "v"(mb[0]), "v"(r1[1]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2[2]) : "v"(mb[1]), "v"(r1[2]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r2[3]) : "v"(mb[1]), "v"(r1[3]));
+  l = __builtin_convertvector(r2, hx4);
+#endif
+}
+__device__ __forceinline__ void orl_split1x3(float x, hx_t& h, hx_t& m, hx_t& l) {
+  h = (hx_t)x;
+  const float r1 = x - (float)h;
+  m = (hx_t)r1;
+  l = (hx_t)(r1 - (float)m);
+}
 // bit j = (z[j] > 0): on the fp32 bit patterns read as signed integers, clamp(bits, 0, 1) is 1 exactly for positive non-zero values
 // (v_med3_i32; -0, +0 and negative values give 0) -- 7 instructions instead of 4 compares + 4 selects + 3 ors
 // ReLU in place + the 4 mask bits on the integer view of the floats: max(bits, 0) is ReLU (negative floats, -0 included, are negative

@@ -58,7 +58,14 @@ struct WsFwdP {
   const unsigned int* dmask; long dm_s0, dm_s1; int dm_g;
   int f32;                                              // exact fp32 arithmetic (v_mfma_f32_16x16x4_f32) instead of the split 16-bit planes
   const float* gscale;                                  // DG, split precision: dynamic power-of-two scale of the gradient rows X, one float per run (z0); null = 1
+  // precision 2 (ws_fwd3_kernel: three fp16 planes; fused first layer + fused tail, top activation not stored): a workgroup owns half of the
+  // columns, so the tail comes out as two partial sums -- half 0 writes tq (with the tail bias), half 1 tq2[z][m] (k_tail_add folds it in);
+  // `dump`: WS_DUMP_SLOTS scratch lines of WS_N floats for the h0 blocks a half computes but does not own
+  int np3;
+  float* tq2; long tq2_s0, tq2_s1;
+  float* dump;
 };
+enum { WS_DUMP_SLOTS = 8192 };
 
 #ifndef WS_WAVES
 #define WS_WAVES 8      // 16 waves (16 columns each) measured slower: the 128-VGPR budget spills
@@ -121,6 +128,15 @@ static inline bool ws_fwd01_supported(const WsFwdP& p) {      // extra condition
   return true;
 }
 hipError_t launch_ws_fwd(WsFwdP p, int nz, hipStream_t st, const WsGeom& geo);      // ws_fwd.hip
+// precision 2: LDS = A image [2][hi, mid, lo][32][256] + tail partial sums + mask nibbles of h1 / h0 + narrow input rows (three planes) + bias / tail weights
+static constexpr size_t ws_fwd3_lds_bytes() {
+  return (size_t)2 * 3 * WS_ROWS * WS_PITCH * 2 + sizeof(float) * 2 * WS_NW * WS_ROWS + 2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_ROWS * 52 +
+         2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_N;
+}
+static inline bool ws_fwd3_supported(const WsFwdP& p, int K, int N) {
+  return ws_fwd_supported(p, K, N) && ws_fwd01_supported(p) && p.tq && !p.Y && p.w_sk == 1 && !p.dmask && !p.x0_discard && p.tq2 && p.dump;
+}
+hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st);              // ws_fwd3.hip (grid.y = 2 column halves)
 
 // =====================================================================================================================
 // ws_dgrad_w0: backward through the top hidden layer of a single-output net, fused with the layer-0 weight gradient.
@@ -178,6 +194,15 @@ static inline int ws_dgrad_blocks(int M, int nz, int max_slab, const WsGeom& geo
   return ws_blocks_per_problem(M / WS_ROWS, nz, prologue, max_slab, geo);
 }
 hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st);      // ws_dgrad.hip
+// precision 2 (three fp16 planes): the W0 flavour from mask bits only; a workgroup owns half of the net's columns (grid.y = 2), so the launch has
+// 2 * per_z workgroups per problem and per_z split-K slabs (ws_dgrad3.hip)
+static constexpr size_t ws_dgrad3_lds_bytes() {
+  return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 3 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
+}
+static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {
+  return ws_dgrad_supported(p, K, N) && !p.Z && p.w0_out && !p.C;
+}
+hipError_t launch_ws_dgrad3_w0(WsDgradP p, int nz, int per_z, hipStream_t st);     // ws_dgrad3.hip
 
 // =====================================================================================================================
 // ws_wgrad: weight gradient of the top hidden layer of a single-output net, output-stationary (+ the tail layer's gradients).
@@ -225,11 +250,12 @@ struct WsWgradP {
   unsigned long long* lab_clk;                                 // lab builds (-DSB_LAB_CLOCK): shader-clock stamps of workgroup (0, 0, 0)
   int M, nz1, groups;
   int f32;                                                     // exact fp32 arithmetic (ws_wgrad32_kernel) instead of the split 16-bit planes
+  int np3;                                                     // precision 2: three fp16 planes of G (ws_wgrad_kernel<5>; derived-tail flavour only), overrides f32
   const float* gscale;                                         // split precision: dynamic power-of-two scale applied to dq / dZ, one float per run (z0); null = 1
 };
 enum { WW_IMG = WS_ROWS * WS_K };                               // bf16 elements of one [32][256] LDS image
-static constexpr size_t ws_wgrad_lds_bytes(bool plain = false, bool recompute = false) {   // 2 buffers x {mask, G hi, G lo} (plain: {dZ hi, dZ lo, H hi, H lo}) + dq / ones blocks (+ the narrow input rows)
-  return (size_t)2 * (plain ? 4 : 3) * WW_IMG * 2 + (size_t)2 * 2 * WS_ROWS * 16 * 2 + (recompute ? sizeof(float) * 2 * WS_ROWS * WS_XLP : 0);
+static constexpr size_t ws_wgrad_lds_bytes(bool plain = false, bool recompute = false, bool p3 = false) {   // 2 buffers x {mask, G hi, G lo} (plain: {dZ hi, dZ lo, H hi, H lo}; p3: {mask, G hi, G mid, G lo}) + dq / ones blocks (+ the narrow input rows)
+  return (size_t)2 * ((plain || p3) ? 4 : 3) * WW_IMG * 2 + (size_t)2 * (p3 ? 3 : 2) * WS_ROWS * 16 * 2 + (recompute ? sizeof(float) * 2 * WS_ROWS * WS_XLP : 0);
 }
 
 static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
@@ -240,6 +266,7 @@ static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
     return aligned16(p.H0) && !(p.h0_pitch & 3) && !(p.h0_s0 & 3) && !(p.h0_s1 & 3);
   }
   if (K != WS_K || N != WS_N || p.M < 256 || (p.M % WS_ROWS) || !p.abits || p.ab_g != 8) return false;
+  if (p.np3 && (p.H1 || !p.W1)) return false;
   if (!aligned16(p.H0) || (p.h0_pitch & 3) || (p.h0_s0 & 3) || (p.h0_s1 & 3)) return false;
   if (!p.H1 && p.W1 && (!p.b1 || !p.dwt || !p.dbt)) return false;
   if (p.H1 && (!aligned16(p.H1) || (p.h1_pitch & 3) || (p.h1_s0 & 3) || (p.h1_s1 & 3) || !p.dwt || !p.dbt)) return false;

@@ -150,11 +150,14 @@ __device__ __forceinline__ void ww_finish(const WsWgradP& p, float* ws_smem, con
 // MODE 0: dW1 / db1 only, 1: h1 streamed for the tail gradients, 2: tail gradients derived from the accumulators,
 //      3: PLAIN -- a materialised dZ instead of (mask, dq, w_tail): A gets a lo plane (three products per block), B = H0 itself
 //      4: PLAIN with H0 = relu(X0 W0^T + b0) recomputed per row group from the narrow input instead of streamed (WsWgradP::X0)
+//      5: mode 2 at precision 2 -- G = dq (.) h0 in THREE fp16 planes (exact for an fp32 product on the planes' grid), three products per
+//         block (the mask operand is exact in one plane): LDS planes {mask, G hi, G mid, G lo}
 template <int MODE>
 __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "8 waves x 32 columns, 32-row groups");
-  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3 || MODE == 4), RECOMP = (MODE == 4);
-  constexpr int NPL = PLAIN ? 4 : 3;                                // LDS planes per buffer
+  constexpr bool TAILS = (MODE == 1), PLAIN = (MODE == 3 || MODE == 4), RECOMP = (MODE == 4), P3 = (MODE == 5);
+  constexpr int NPL = (PLAIN || P3) ? 4 : 3;                        // LDS planes per buffer
+  constexpr int DQP = P3 ? 3 : 2;                                   // planes of the dq block (bias-gradient operand)
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   hx_t* img = (hx_t*)ws_smem;                                   // [buf][{mask, G hi, G lo}][32][256]   (PLAIN: {dZ hi, dZ lo, H hi, H lo})
   __shared__ u32x2_t mlut[16];                                      // 4 mask bits -> 4 bf16 values
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   hx_t* dqimg = img + 2 * NPL * WW_IMG;                            // [buf][hi, lo][32 rows][16]: column 0 = dq (PLAIN: 1), others 0 (db1 operand)
   // ---- RECOMP: first-layer fragments of this wave's 32 columns (K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond) and the
   // staging of the narrow input rows -- ws_fwd_kernel<., L0>'s producer, writing into this kernel's H image ----
-  float* Xl = (float*)(dqimg + 2 * 2 * WS_ROWS * 16);               // [buf][32][WS_XLP]: hi plane in 16-bit slots 0..31, lo plane in 32..63 of a row
+  float* Xl = (float*)(dqimg + 2 * DQP * WS_ROWS * 16);             // [buf][32][WS_XLP]: hi plane in 16-bit slots 0..31, lo plane in 32..63 of a row
   const float* __restrict__ X0g = RECOMP ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
   hx8 b0h[2], b0l[2];
   if (RECOMP) {
@@ -310,6 +313,22 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       return;
     }
     const float dqs = sdq[i] * gsc;
+    if (P3) {
+      hx4 m;
+      hx_t* g3 = img + (long)buf * NPL * WW_IMG + WW_IMG;
+      orl_split4x3(s0[i] * dqs, h, m, l);
+      *(hx4*)(g3 + o) = h;
+      *(hx4*)(g3 + WW_IMG + o) = m;
+      *(hx4*)(g3 + 2 * WW_IMG + o) = l;
+      if (kq == 0) {
+        hx_t hh, mm, ll;
+        orl_split1x3(dqs, hh, mm, ll);
+        hx_t* dqi = dqimg + (long)buf * DQP * WS_ROWS * 16;
+        dqi[r * 16] = hh; dqi[WS_ROWS * 16 + r * 16] = mm; dqi[2 * WS_ROWS * 16 + r * 16] = ll;
+        dqsum += sdq[i];
+      }
+      return;
+    }
     orl_split4(s0[i] * dqs, h, l);
     *(hx4*)(gh + o) = h;
     *(hx4*)(gl + o) = l;
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) store_piece(buf, i);
   };
-  if (!TAILS) for (int e = tid; e < 2 * 2 * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
+  if (!TAILS) for (int e = tid; e < 2 * DQP * WS_ROWS * 16 / 2; e += WS_NT) ((unsigned int*)dqimg)[e] = 0u;   // columns 1..15 stay zero
   if (PLAIN) {                                                     // db = dZ^T 1: column 0 of the hi block = 1.0 for every row, both buffers
     __syncthreads();
     if (tid < 2 * WS_ROWS) (dqimg + (long)(tid >> 5) * 2 * WS_ROWS * 16)[(tid & 31) * 16] = (hx_t)1.0f;
@@ -369,9 +388,10 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
     const bool more = steady || g + gs < p.groups, more2 = steady || g + 2 * gs < p.groups;
     const hx_t* mi = img + (long)buf * NPL * WW_IMG;
     const hx_t* ml = mi + WW_IMG;                                    // PLAIN: lo plane of dZ
-    const hx_t* gh = mi + (NPL - 2) * WW_IMG;
-    const hx_t* gl = gh + WW_IMG;
-    const hx_t* dqi = dqimg + (long)buf * 2 * WS_ROWS * 16;
+    const hx_t* gh = mi + (P3 ? 1 : NPL - 2) * WW_IMG;
+    const hx_t* gl = gh + (P3 ? 2 : 1) * WW_IMG;
+    const hx_t* gm = gh + WW_IMG;                                    // P3: the middle plane
+    const hx_t* dqi = dqimg + (long)buf * DQP * WS_ROWS * 16;
     {
       // one v_mfma_f32_16x16x32_bf16 covers the whole 32-row group: its 8 k-values per lane are the two transposed reads of
       // rows 4 lq .. + 3 and 16 + 4 lq .. + 3 (the k order is free as long as A and B agree)
@@ -380,19 +400,22 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
         *(s16x4*)&r = x; *((s16x4*)&r + 1) = y;
         return r;
       };
-      hx8 bh[2], bl[2];
+      hx8 bh[2], bl[2], bm[2];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) {
         bh[nb] = cat(ww_tr(gh, 0, ncol0 + 16 * nb, lane), ww_tr(gh, 16, ncol0 + 16 * nb, lane));
         bl[nb] = cat(ww_tr(gl, 0, ncol0 + 16 * nb, lane), ww_tr(gl, 16, ncol0 + 16 * nb, lane));
+        if (P3) bm[nb] = cat(ww_tr(gm, 0, ncol0 + 16 * nb, lane), ww_tr(gm, 16, ncol0 + 16 * nb, lane));
       }
       const int dro0 = (4 * lq + (li >> 2)) * 16 + 4 * (li & 3), dro1 = dro0 + 16 * 16;
       typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-      hx8 bdh, bdl;
+      hx8 bdh, bdl, bdm;
       if (!TAILS) {
         bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
-        bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
-                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
+        bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro0)),
+                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro1)));
+        if (P3) bdm = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
+                          __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
       }
 #pragma unroll
       for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
@@ -403,6 +426,12 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
         for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bl[nb], acc[kb0][nb]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bl[nb], acc[kb1][nb]);
+        if (P3) {                                                    // mask * mid(G)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[kb0][nb] = ORL_MFMA_16x16x32(a0, bm[nb], acc[kb0][nb]);
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bm[nb], acc[kb1][nb]);
+        }
         if (PLAIN) {                                                 // lo(dZ) * hi(H)
           const hx8 l0 = cat(ww_tr(ml, 0, 16 * kb0, lane), ww_tr(ml, 16, 16 * kb0, lane));
           const hx8 l1 = cat(ww_tr(ml, 0, 16 * kb1, lane), ww_tr(ml, 16, 16 * kb1, lane));
@@ -426,6 +455,10 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
           } else {
             accb[0] = ORL_MFMA_16x16x32(c0, bdl, accb[0]);
             accb[1] = ORL_MFMA_16x16x32(c1, bdl, accb[1]);
+            if (P3) {
+              accb[0] = ORL_MFMA_16x16x32(c0, bdm, accb[0]);
+              accb[1] = ORL_MFMA_16x16x32(c1, bdm, accb[1]);
+            }
           }
           accb[0] = ORL_MFMA_16x16x32(c0, bdh, accb[0]);
           accb[1] = ORL_MFMA_16x16x32(c1, bdh, accb[1]);
@@ -457,7 +490,7 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
   for (; g < p.groups; g += gs, ++it) iteration(g, it, false);
   WS_STAMP(3);
 
-  ww_finish<(MODE == 4 ? 3 : MODE)>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
+  ww_finish<(MODE == 4 ? 3 : (MODE == 5 ? 2 : MODE))>(p, ws_smem, acc, accb, tacc, bacc, dqsum, wtg, z0, z1, ncol0, 1.0f / gsc);
   WS_STAMP(4);
 }
 
@@ -704,6 +737,7 @@ hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes());
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes(true, true));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad32_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad32_lds_bytes(true));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_wgrad_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_wgrad_lds_bytes(false, false, true));
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
@@ -716,6 +750,10 @@ hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st) {
   if (p.dZ) {                                      // plain (materialised) gradient: a hidden layer below the top one
     if (p.f32) hipLaunchKernelGGL(ws_wgrad32_kernel<3>, grid, block, ws_wgrad32_lds_bytes(), st, p);
     else hipLaunchKernelGGL(ws_wgrad_kernel<3>, grid, block, ws_wgrad_lds_bytes(true), st, p);
+    return hipGetLastError();
+  }
+  if (p.np3) {                                     // precision 2: three G planes (the derived-tail flavour only: ws_wgrad_supported)
+    hipLaunchKernelGGL(ws_wgrad_kernel<5>, grid, block, ws_wgrad_lds_bytes(false, false, true), st, p);
     return hipGetLastError();
   }
   if (p.f32) {

@@ -124,11 +124,13 @@ class EnginePolicy(BasePolicy):
         gives (custom initialisations such as run_iql.py:121-125 / run_edac.py:100-103 need ``run_init``).
         ``seed``: key of the device sampler / noise streams (default: derived from ``torch.initial_seed()`` and a per-process
         bind counter, so launcher seeds give independent streams and a re-bind never replays one).
-        ``precision``: 0 exact fp32 MFMA (default), 1 split-bf16 MFMA (same 1e-4 parity gate on losses and Q-values, ~3x faster at many runs)."""
+        ``precision``: 0 exact fp32 MFMA (default); 1 split-fp16 MFMA (two planes per operand: same 1e-4 parity gate on losses and Q-values, ~3x
+        faster at many runs); 2 three fp16 planes per operand in the many-row critic launches (an fp32 operand is represented exactly: fp32-class
+        arithmetic at about twice the fp32 MFMA rate), exact fp32 MFMA everywhere else."""
         if n_runs is not None and n_runs < 1:
             raise ValueError("n_runs must be >= 1")
-        if precision is not None and precision not in (0, 1):
-            raise ValueError("precision must be 0 (fp32 MFMA) or 1 (split-bf16 MFMA)")
+        if precision is not None and precision not in (0, 1, 2):
+            raise ValueError("precision must be 0 (fp32 MFMA), 1 (split-fp16 MFMA) or 2 (three fp16 planes / fp32 MFMA)")
         if self._eng is not None:
             # an engine exists: the next bind restores parameters, Adam moments, step count and scalars of every run that survives
             # (all of them when n_runs is unchanged; the first n_runs when it shrinks; new runs r >= old n_runs start fresh)
