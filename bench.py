@@ -16,7 +16,8 @@ all_gather of the per-run metric means at the end, as MFPolicyTrainer would log 
 
 The timed block of K steps (barrier + synchronize on both sides, max over ranks) is repeated (>= 5 blocks and
 >= 2 s, --min-reps / --min-seconds); `value` is the median block, every block is listed in `reps`.
-Side records of the same run (rank 0, N = 1 only): `value_fp32` / `fp32` (exact-fp32 MFMA, same workload), `target`
+Side records of the same run (rank 0, N = 1 only): `value_fp32` / `fp32` (exact-fp32 MFMA, same workload, one engine x 128 runs),
+`value_fp32_class` / `fp32_class` (precision 2: three fp16 planes per operand in the critic launches, fp32 MFMA elsewhere; same geometry), `target`
 (both over the north_star's 50k), `by_runs` (runs per GPU 1 .. 192), `other_configs` (TD3BC, IQL = BASELINE configs[2], EDAC =
 configs[3]; 128 runs each), `api` (a fused MFPolicyTrainer epoch through offlinerlkit.policy.CQLPolicy / ReplayBuffer with the split
 products selected), `api_default` (the same epoch with NO engine options set: what a user of the reference's API gets untouched -- one run,
@@ -49,12 +50,19 @@ OBS, ACT, HIDDEN, BATCH, NREP = 17, 6, [256, 256], 256, 10
 TARGET_STEPS_PER_S = 50_000.0       # BASELINE.json north_star: >= 50k CQL gradient-steps/s on one MI355X
 # MI355X_MICROARCH.md: fp32 MFMA dense peak 157.3 TFLOP/s; bf16 / fp16 MFMA dense peak ~2500 TFLOP/s.  precision=1 spends three
 # 16-bit MFMAs per fp32-equivalent product, so its ceiling for ALGORITHMIC flops is 2500/3.
-PEAK_TFLOPS = {0: 157.3, 1: 2500.0 / 3.0}
+# precision=2: six 16-bit MFMAs per fp32-equivalent product in the launches that carry the matrix work (three planes per operand): 2500/6.
+PEAK_TFLOPS = {0: 157.3, 1: 2500.0 / 3.0, 2: 2500.0 / 6.0}
 
 
 def dtype_string(precision):
     if precision == 0:
         return "f32 (v_mfma_f32_16x16x4_f32: the reference's arithmetic)"
+    if precision == 2:
+        return ("f32 storage / accumulate, fp32-class products: in the many-row critic launches every operand = THREE fp16 planes (hi + mid + lo = 33 "
+                "significand bits: an fp32 operand is represented exactly) and the six products hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi on "
+                "v_mfma_f32_16x16x32_f16 drop only terms below 2^-33 of a product; every other launch on v_mfma_f32_16x16x4_f32.  Held to the exact-fp32 "
+                "bars of the parity tests (tests/test_gpu_cql.py: losses 1e-4 vs the reference fixtures, per-element parameter bars; "
+                "tests/test_gpu_grads.py / test_gpu_backward_f64.py: the precision-0 constants)")
     from offlinerlkit import _engine
     if _engine.split_bits() >= 22:
         return ("f32 storage / accumulate; products on split-fp16 MFMA (every operand = fp16 hi + fp16 lo plane = 22 significand bits, power-of-two "
@@ -468,7 +476,7 @@ def main():
     ap.add_argument("--engines-per-gpu", type=int, default=None,
                     help="independent engines per GPU (each --runs-per-gpu runs, own HIP stream and host thread): the launch-latency-bound "
                          "256-row phases of one engine overlap the many-row launches of the other (default 2)")
-    ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split MFMA (fp16 hi + lo planes; bf16 planes in the variant build) (parity-gated)")
+    ap.add_argument("--precision", type=int, default=int(os.environ.get("ORL_PRECISION", "1")), help="0 exact fp32 MFMA, 1 split MFMA (fp16 hi + lo planes; bf16 planes in the variant build), 2 three fp16 planes in the critic launches / fp32 MFMA elsewhere (all parity-gated)")
     ap.add_argument("--min-reps", type=int, default=5)
     ap.add_argument("--min-seconds", type=float, default=2.0)
     ap.add_argument("--no-sides", action="store_true", help="skip fp32 / by_runs / other_configs side records")
@@ -587,7 +595,7 @@ def main():
             g.close()
         engines = []
         sides = world == 1 and not args.no_sides and (od, ad) == (OBS, ACT)
-        by_runs, fp32, others = None, None, None
+        by_runs, fp32, fp32_class, others = None, None, None, None
         api, api_default, config5 = None, None, None
         if sides:
             by_runs = []                                 # (single side engines run alone on the GPU: whole rounds of workgroups)
@@ -600,19 +608,26 @@ def main():
                 by_runs.append(dict(runs_per_gpu=r_side, engines_per_gpu=1, value=r_side * n_side / d, ms_per_step=d / n_side * 1e3))
                 es[0].close()
             by_runs.append(dict(runs_per_gpu=R * E, engines_per_gpu=E, value=value, ms_per_step=dt_med / args.steps * 1e3))
-            if args.precision != 0:
-                es = make_cql_engines(E, R, local_rank, 0, 7, buf)
+            # the same workload in the reference's own arithmetic and in fp32-CLASS arithmetic, each in its own best geometry (one engine x 128
+            # runs, whole rounds of 256 workgroups): `fp32` = exact fp32 MFMA everywhere (precision 0), `fp32_class` = three fp16 planes per
+            # operand in the many-row critic launches, fp32 MFMA elsewhere (precision 2)
+            def side_precision(prec, n_steps, seed):
+                es = make_cql_engines(1, 128, local_rank, prec, seed, buf)
                 learn_all(es, 10)
-                n32 = 20
-                rr = timed_rate(es, n32, 1.2, min_reps=3)
+                rr = timed_rate(es, n_steps, 1.2, min_reps=3)
                 d = float(np.median(rr))
-                r32 = profile_roofline(es[0], 5, 0, R)
-                if r32:
-                    r32.pop("table", None)
-                fp32 = dict(value=R * E * n32 / d, unit="gradient-steps/s", ms_per_step=d / n32 * 1e3, dtype=dtype_string(0), steps_per_block=n32,
-                            reps_s=rr, seconds_timed=float(np.sum(rr)), engines_per_gpu=E, runs_per_engine=R, roofline=r32)
+                rf = profile_roofline(es[0], 5, prec, 128)
+                if rf:
+                    rf.pop("table", None)
+                rec = dict(value=128 * n_steps / d, unit="gradient-steps/s", ms_per_step=d / n_steps * 1e3, dtype=dtype_string(prec), precision=prec,
+                           steps_per_block=n_steps, reps_s=rr, seconds_timed=float(np.sum(rr)), engines_per_gpu=1, runs_per_engine=128, roofline=rf)
                 for g in es:
                     g.close()
+                return rec
+            if args.precision != 0:
+                fp32 = side_precision(0, 20, 7)
+            if args.precision != 2:
+                fp32_class = side_precision(2, 40, 8)
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
             # the drop-in number: CQLPolicy exactly as run_cql.py:80-128 builds it -- one policy, no set_engine_options (n_runs 1, the product's
@@ -643,8 +658,11 @@ def main():
             "dtype": dtype_string(args.precision),
             # the same workload in the reference's own arithmetic (exact fp32 MFMA), measured in this run, next to the headline
             "value_fp32": (value if args.precision == 0 else (fp32["value"] if fp32 else None)),
+            # ... and in fp32-class arithmetic (precision 2: exact fp32 operands as three fp16 planes, products down to 2^-33, fp32 accumulation)
+            "value_fp32_class": (value if args.precision == 2 else (fp32_class["value"] if fp32_class else None)),
             "target": {"steps_per_s": TARGET_STEPS_PER_S, "value_over_target": value / world / TARGET_STEPS_PER_S,
                        "value_fp32_over_target": ((value / world if args.precision == 0 else fp32["value"]) / TARGET_STEPS_PER_S) if (fp32 or args.precision == 0) else None,
+                       "value_fp32_class_over_target": ((value / world if args.precision == 2 else fp32_class["value"]) / TARGET_STEPS_PER_S) if (fp32_class or args.precision == 2) else None,
                        "note": "BASELINE.json north_star target, per GPU; published reference numbers: none (vs_baseline null)"},
             "data": "synthetic D4RL-shaped replay buffer (N(0,1) obs, tanh actions), random-init weights",
             "config": {"workload": ("CQL halfcheetah-medium-v2 shape: obs17/act6, batch 256, MLP [256,256], 10 repeat actions, "
@@ -660,7 +678,7 @@ def main():
                        "dist_backend": backend if world > 1 else None},
             "reps": {"blocks": len(reps), "steps_per_block": args.steps, "block_seconds": reps, "value_is": "median block",
                      "value_min": total_steps / max(reps), "value_max": total_steps / min(reps), "seconds_timed": float(np.sum(reps))},
-            "roofline": roof, "cpu_baseline": cpu, "fp32": fp32, "by_runs": by_runs, "other_configs": others, "api": api,
+            "roofline": roof, "cpu_baseline": cpu, "fp32": fp32, "fp32_class": fp32_class, "by_runs": by_runs, "other_configs": others, "api": api,
             "api_default": api_default, "config5_per_gpu": config5,
             "single_run": by_runs[0] if by_runs else None,
             "metrics_gathered": {"shape": list(metrics_all.shape), "loss_critic1_mean_per_rank": [float(x) for x in metrics_all[:, :, 1].mean(axis=1)]},

@@ -38,7 +38,7 @@ def _blown_up_case(run, R):
     return cfg, st, big, b, noises[0], ocql
 
 
-@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("precision", [0, 1, 2])
 def test_activation_beyond_the_split_range_passes_in_fp32_and_is_reported_in_split_precision(precision):
     from offlinerlkit import _engine
     R, bad = 3, 1
