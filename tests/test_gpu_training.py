@@ -129,7 +129,7 @@ def train(algo, ds, tmp_path, precision, n_runs, epochs, steps):
     return pol, head, col
 
 
-@pytest.mark.parametrize("algo,precision", [("td3bc", 1), ("td3bc", 0), ("iql", 1), ("cql", 1), ("cql", 0), ("edac", 1)])
+@pytest.mark.parametrize("algo,precision", [("td3bc", 1), ("td3bc", 0), ("iql", 1), ("cql", 1), ("cql", 0), ("cql", 2), ("edac", 1)])
 def test_offline_training_improves_on_the_behaviour_policy(task, tmp_path, algo, precision):
     ds, random_ret, behaviour_ret = task
     assert random_ret < behaviour_ret < -8.0                                   # the task is what the docstring says

@@ -260,3 +260,26 @@ def test_trainer_logs_and_checkpoints_every_run_of_a_multi_run_policy(tmp_path):
     r0, r2 = float(row["run0/eval/episode_reward"]), float(row["run2/eval/episode_reward"])
     assert r2 > r0
     assert float(row["loss/a"]) == 2.0 and pol.cur == 0
+
+
+def test_engine_options_accept_the_three_precisions_and_refuse_others():
+    """``set_engine_options(precision=...)``: 0 exact fp32, 1 two fp16 planes, 2 three fp16 planes in the critic launches (no engine is built until
+    the first ``learn``: this runs without a GPU)"""
+    import pytest
+    from offlinerlkit.modules import ActorProb, Critic, TanhDiagGaussian
+    from offlinerlkit.nets import MLP
+    from offlinerlkit.policy import CQLPolicy
+    import torch
+    actor = ActorProb(MLP(17, [256, 256]), TanhDiagGaussian(256, 6, unbounded=True, conditioned_sigma=True))
+    c1, c2 = Critic(MLP(23, [256, 256])), Critic(MLP(23, [256, 256]))
+    adam = lambda m: torch.optim.Adam(m.parameters(), lr=3e-4)
+
+    class Space:
+        low, high, shape = -np.ones(6, np.float32), np.ones(6, np.float32), (6,)
+    pol = CQLPolicy(actor, c1, c2, adam(actor), adam(c1), adam(c2), action_space=Space(), tau=0.005, gamma=0.99, alpha=0.2)
+    for prec in (0, 1, 2):
+        assert pol.set_engine_options(precision=prec, n_runs=2) is pol and pol._precision == prec and pol.n_runs == 2
+    with pytest.raises(ValueError, match="precision must be 0"):
+        pol.set_engine_options(precision=3)
+    with pytest.raises(ValueError, match="n_runs"):
+        pol.set_engine_options(n_runs=0)
