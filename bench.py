@@ -628,6 +628,14 @@ def main():
                 fp32 = side_precision(0, 20, 7)
             if args.precision != 2:
                 fp32_class = side_precision(2, 40, 8)
+                fp32_class["by_runs"] = []                 # few runs per engine in fp32-class arithmetic (exact fp32: 3.7k at 1 run, 11.8k at 8)
+                for r_side in (1, 8):
+                    es = make_cql_engines(1, r_side, local_rank, 2, 200 + r_side, buf)
+                    learn_all(es, 30)
+                    n_side = max(50, min(2000, int(4000 / r_side)))
+                    d = float(np.median(timed_rate(es, n_side, 0.6)))
+                    fp32_class["by_runs"].append(dict(runs_per_gpu=r_side, engines_per_gpu=1, value=r_side * n_side / d, ms_per_step=d / n_side * 1e3))
+                    es[0].close()
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
             # the drop-in number: CQLPolicy exactly as run_cql.py:80-128 builds it -- one policy, no set_engine_options (n_runs 1, the product's
