@@ -43,8 +43,10 @@ def test_bench_prints_one_contract_line():
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
 
 
-def test_two_engines_in_the_one_round_geometry_match_their_solo_runs():
-    """The combination bench.py's default actually runs: TWO engines per GPU, each created with `ws_one_round = 1`
+@pytest.mark.parametrize("precision", [1, 2])
+def test_two_engines_in_the_one_round_geometry_match_their_solo_runs(precision):
+    """(precision 2: the three-plane launches -- two column-half workgroups per net and slab, their own scratch lines per engine.)
+    The combination bench.py's default actually runs: TWO engines per GPU, each created with `ws_one_round = 1`
     (weight-stationary launches on CUs / nets workgroups per net), each on its own HIP stream and host thread, sampling the same HBM buffer
     concurrently.  Engines are independent, so what an engine computes must not depend on what runs beside it: 20 device-sampled steps of
     both engines side by side give bit-identical metrics and parameters to the same two engines (same seeds) stepped one after the other."""
@@ -60,7 +62,7 @@ def test_two_engines_in_the_one_round_geometry_match_their_solo_runs():
     buf.load(ds["obs"], ds["act"], ds["nobs"], ds["rew"], ds["term"])
 
     def make():
-        es = [bw.make_engine("cql", R, 1, 0, 40 + e, ws_one_round=1) for e in range(2)]
+        es = [bw.make_engine("cql", R, precision, 0, 40 + e, ws_one_round=1) for e in range(2)]
         for g in es:
             g.attach_buffer(buf)
         return es

@@ -304,7 +304,7 @@ def test_cql_fp32_weight_stationary_kernels_match_tiled_kernels(monkeypatch):
 
 
 @pytest.mark.parametrize("R", [2, 16, 96])
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_identical_cql_runs_stay_bit_identical(precision, R):
     """No arrival-order arithmetic in the CQL step either (one-launch loss with its last-arriver reduction, split-K slabs summed by Adam in
     slab order, weight-stationary kernels with one slab per workgroup): runs given identical parameters, batches and noise report
