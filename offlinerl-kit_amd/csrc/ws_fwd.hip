@@ -1,4 +1,7 @@
 // ws_fwd.hip — weight-stationary forward of the 256-wide layers (+ fused first layer, tail, mask bits; plain-dgrad mode) (interface and design notes: ws_gemm.h).
+#ifdef WS_FWD_WAVES16      // lab: sixteen waves (16 columns each, four per SIMD, <= 128 VGPRs) for this translation unit only
+#define WS_WAVES 16
+#endif
 #include "ws_device.h"
 
 namespace orl {
@@ -298,15 +301,14 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
   };
   auto epilogue = [&](const f32x4 (&acc)[WS_SUB][WS_CB], int g, int par) __attribute__((always_inline)) {
     if (DG) {                                      // gradient epilogue: ReLU mask of the receiving activation from its packed bits
-      static_assert(!DG || WS_CB == 2, "one 32-column mask word per wave");
       const unsigned int* __restrict__ dm = p.dmask + z0 * p.dm_s0 + z1 * p.dm_s1;
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) {
         const long m = (long)g * WS_ROWS + 16 * s + li;
-        const unsigned int w = dm[m * p.dm_g + wave];
+        const unsigned int w = dm[m * p.dm_g + (ncol0 >> 5)];              // the 32-column mask word that holds this wave's columns
 #pragma unroll
         for (int cb = 0; cb < WS_CB; ++cb) {
-          const unsigned int nib = w >> (16 * cb + 4 * lq);
+          const unsigned int nib = w >> ((ncol0 & 31) + 16 * cb + 4 * lq);
           f32x4 v = acc[s][cb];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? (F32 ? v[r] : v[r] * inv_sc) : 0.f;
@@ -362,8 +364,26 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     // staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue; 4..7: the four blocks of the next
     // group's first layer (or the four staging pieces of the plain variant).
     auto piece = [&](int ks) __attribute__((always_inline)) {
-      static_assert(WS_SUB == 2 && WS_CB == 2 && WS_LD == 4, "eight pieces");
+      static_assert(WS_SUB == 2 && ((WS_CB == 2 && WS_LD == 4) || (WS_CB == 1 && WS_LD == 2)), "eight (four) pieces");
       const int par = (it - 1) & 1;
+      if constexpr (WS_CB == 1) {        // sixteen waves: two epilogue blocks (k steps 0, 2), two first-layer blocks / staging pieces (4, 6)
+        if (ks == 0 || ks == 2) {
+          const int s = ks >> 1;
+          fpart = 0.f;
+          epi_block(pacc[s][0], g - gs, par, s, 0, fpart);
+          epi_row(par, s, fpart);
+        } else if (ks == 4 || ks == 6) {
+          const int s = (ks - 4) >> 1;
+          if (L0) {
+            prod_x((it + 1) & 1, s, fxah, fxal);
+            prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, 0, fxah, fxal);
+          } else {
+            store_group(buf ^ 1, stn, s, s + 1);
+            load_piece(g + 2 * gs, stn, s);
+          }
+        }
+        return;
+      }
       if (ks < 4) {
         const int s = ks >> 1, cb = ks & 1;
         if (cb == 0) fpart = 0.f;
