@@ -13,7 +13,7 @@ import test_gpu_cql as tc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_engine_stays_inside_the_reference_envelope_for_200_steps(precision):
     from offlinerlkit import _engine
     keys, ref, perturbed = lh.load()
@@ -26,7 +26,7 @@ def test_engine_stays_inside_the_reference_envelope_for_200_steps(precision):
             m = eng.step(tc.lead(b, R), tc.lead(tc.noise_list(n), R))
             assert np.array_equal(m[0], m[1])                     # identical inputs, identical runs: bit-identical metrics
             losses.append(m[0])
-        what = "exact-fp32 engine" if precision == 0 else f"split engine ({_engine.split_bits()}-bit operands)"
+        what = {0: "exact-fp32 engine", 2: "three-plane engine (precision 2)"}.get(precision, f"split engine ({_engine.split_bits()}-bit operands)")
         lh.check(what, np.array(losses, np.float64), ref, perturbed)
         for r in range(R):
             for net in (0, 1, 2):

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 O=$PWD/gpurun_out/prof_r04
 mkdir -p $O
 B="python3 bench.py --steps 20 --warmup 5 --no-sides --no-cpu-baseline --profile-steps 0 --min-reps 1 --min-seconds 0"
-what=${1:-all}      # all | cql | few | algos
+what=${1:-all}      # all | cql | few | algos | p2
 if [ "$what" = all ] || [ "$what" = cql ]; then
   echo "== default 2x96: kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/default_stats -o r -- $B > $O/default_stats.log 2>&1
   echo "== 1x128: kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/1x128_stats -o r -- $B --engines-per-gpu 1 --runs-per-gpu 128 > $O/1x128_stats.log 2>&1
@@ -38,6 +38,16 @@ if [ "$what" = all ] || [ "$what" = algos ]; then
       rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/${a}_$c -o r -- python3 tools/algo_run.py $a 128 1 30 > $O/${a}_$c.log 2>&1
     done
   done
+fi
+if [ "$what" = all ] || [ "$what" = p2 ]; then
+  P2="$B --engines-per-gpu 1 --runs-per-gpu 128 --precision 2"
+  echo "== precision 2, 1x128: kernel stats"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/p2_stats -o r -- $P2 > $O/p2_stats.log 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    echo "== precision 2, 1x128: pmc $c"; rocprofv3 --kernel-trace --output-format csv --pmc $c -d $O/p2_$c -o r -- $P2 > $O/p2_$c.log 2>&1
+  done
+  python3 bench.py --steps 20 --warmup 5 --no-sides --no-cpu-baseline --engines-per-gpu 1 --runs-per-gpu 128 --precision 2 --profile-steps 20 --profile-dump $O/tags_p2_1x128.txt > $O/bench_p2_1x128.json 2> $O/bench_p2_1x128.err
+  python3 tools/few_runs_ab.py "-" --runs 1 8 16 32 128 --precision 0 --reps 2 > $O/few_runs_p0.txt 2>/dev/null
+  python3 tools/few_runs_ab.py "-" --runs 1 8 16 32 128 --precision 2 --reps 2 > $O/few_runs_p2.txt 2>/dev/null
 fi
 # keep what the summaries need (the merge back is capped at 64 MiB): stats csv, counter csv, kernel trace csv of the few-runs passes
 find $O -name "*.db" -delete; find $O -name "*agent_info*" -delete

@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r04")
 DST = os.path.join(ROOT, "profiles")
-SECTIONS = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"cql", "algos", "few"}
+SECTIONS = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else {"cql", "algos", "few", "p2"}
 commit = sys.argv[1] if len(sys.argv) > 1 else subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"]).decode().strip()
 
 
@@ -106,6 +106,21 @@ if sq:
     run_tool("pmc_sq.py", sq, "r04_pmc_sq_counters_1x128.txt",
              f"# SQ counters per kernel (means per dispatch), CQL one engine x 128 runs, split precision (fp16 planes), commit {commit}: three separate rocprofv3 --kernel-trace --pmc passes\n"
              "# (units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_VALU_MFMA_BUSY_CYCLES and SQ_VALU_MFMA_COEXEC_CYCLES count cycles)\n")
+# precision 2 (three fp16 planes in the critic launches, fp32 MFMA elsewhere), one engine x 128 runs
+if "p2" in SECTIONS:
+    copy_stats("p2_stats", "r04_cql_p2_1x128_kernel_stats.csv", f"rocprofv3 --kernel-trace --stats -- {B} --engines-per-gpu 1 --runs-per-gpu 128 --precision 2")
+    for src, name in (("tags_p2_1x128.txt", "r04_hip_event_tags_p2_1x128.txt"), ("bench_p2_1x128.json", "r04_bench_p2_1x128.json")):
+        if os.path.exists(os.path.join(SRC, src)):
+            shutil.copy(os.path.join(SRC, src), os.path.join(DST, name))
+    if one("p2_FETCH_SIZE/**/*counter_collection.csv") and one("p2_WRITE_SIZE/**/*counter_collection.csv"):
+        run_tool("pmc_summary.py", [os.path.join(SRC, "p2_FETCH_SIZE"), os.path.join(SRC, "p2_WRITE_SIZE")], "r04_pmc_summary_p2_1x128.md",
+                 f"## HBM traffic per launch, CQL, one engine x 128 runs, precision 2 (commit {commit})\nseparate `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of `{B} --engines-per-gpu 1 --runs-per-gpu 128 --precision 2`; gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE x 2, counters in KiB)\n\n")
+    parts = []
+    for f, title in (("few_runs_p0.txt", "precision 0 (exact fp32 MFMA)"), ("few_runs_p2.txt", "precision 2 (three fp16 planes in the critic launches, fp32 MFMA elsewhere)")):
+        if os.path.exists(os.path.join(SRC, f)):
+            parts.append(f"## {title}: `tools/few_runs_ab.py - --runs 1 8 16 32 128 --precision ...`\n```\n{open(os.path.join(SRC, f)).read()}```\n")
+    if parts:
+        open(os.path.join(DST, "r04_fp32_class_by_runs.md"), "w").write(f"# CQL gradient-steps/s by runs per engine, fp32-class arithmetic against exact fp32 (one engine, graph replay; commit {commit})\n\n" + "\n".join(parts))
 # few runs
 out = [f"# Kernel nodes per step in the few-runs regime (graph replay; rocprofv3 --kernel-trace, tools/trace_summary.py), commit {commit}\n"]
 for r in ((1, 8) if "few" in SECTIONS else ()):
