@@ -409,14 +409,6 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
       }
       const int dro0 = (4 * lq + (li >> 2)) * 16 + 4 * (li & 3), dro1 = dro0 + 16 * 16;
       typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-      hx8 bdh, bdl, bdm;
-      if (!TAILS) {
-        bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
-        bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro0)),
-                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro1)));
-        if (P3) bdm = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
-                          __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
-      }
 #pragma unroll
       for (int kp = 0; kp < 8; ++kp) {                               // two 16-row k blocks per trip: dependent MFMAs are 4 apart
         const int kb0 = 2 * kp, kb1 = kb0 + 1;
@@ -445,6 +437,13 @@ __global__ __launch_bounds__(WS_NT) void ws_wgrad_kernel(const WsWgradP p) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) acc[kb1][nb] = ORL_MFMA_16x16x32(a1, bh[nb], acc[kb1][nb]);
         if (!TAILS && kp == 7) {                                     // this wave's share of db1: k blocks 2 wave, 2 wave + 1 (own reads: no branch)
+          // (the dq block's fragments are read here, next to their only use: fetched at the top of the iteration they were 8 - 12 more live registers -- mode 2: 4 -> 0 spilled registers, 519 -> 510 us; mode 5: 21 -> 2, 776 -> 706 us at 1 x 128, one-call A/B)
+          hx8 bdh, bdl, bdm;
+          bdh = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro0)), __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + dro1)));
+          bdl = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro0)),
+                    __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + (DQP - 1) * WS_ROWS * 16 + dro1)));
+          if (P3) bdm = cat(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro0)),
+                            __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(dqi + WS_ROWS * 16 + dro1)));
           const hx8 c0 = cat(ww_tr(mi, 0, 32 * wave, lane), ww_tr(mi, 16, 32 * wave, lane));
           const hx8 c1 = cat(ww_tr(mi, 0, 32 * wave + 16, lane), ww_tr(mi, 16, 32 * wave + 16, lane));
           if (PLAIN) {                                               // the ones block has no lo plane; dZ has
