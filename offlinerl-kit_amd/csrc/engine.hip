@@ -475,10 +475,15 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       // precision 2: the fused first + second layer + tail forward of a many-row single-output net has a three-plane flavour (ws_fwd3.hip);
       // its two column halves leave two tail partial sums
       bool fwd3 = false;
-      if (p3(1) && fused0 && want_tail && !w.Y && !w.x0_discard && !l.ens && ws_dump && ws.count("tq_scratch")) {
-        const Mat& sc = ws.at("tq_scratch");
-        if ((long)M <= sc.cs && nr.nz1 <= tq_scratch_nets) {
-          w.np3 = 1; w.tq2 = sc.p; w.tq2_s0 = sc.rs; w.tq2_s1 = sc.cs; w.dump = ws_dump;
+      if (p3(1) && fused0 && !l.ens && ws_dump && (!want_tail || ws.count("tq_scratch"))) {
+        bool room = true;
+        if (want_tail) {
+          const Mat& sc = ws.at("tq_scratch");
+          room = (long)M <= sc.cs && nr.nz1 <= tq_scratch_nets;
+          if (room) { w.tq2 = sc.p; w.tq2_s0 = sc.rs; w.tq2_s1 = sc.cs; }
+        }
+        if (room) {
+          w.np3 = 1; w.dump = ws_dump;
           fwd3 = ws_fwd3_supported(w, in, out);
           if (!fwd3) { w.np3 = 0; w.tq2 = nullptr; w.dump = nullptr; }
         }
@@ -494,7 +499,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       hipError_t err = fwd3 ? launch_ws_fwd3(w, nz, ws_blocks_per_problem(M / WS_ROWS, 2 * nz, 10, 1 << 20, ws_geo), stream) : launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_fwd launch ") + tag + ": " + hipGetErrorString(err));
-      if (fwd3) {
+      if (fwd3 && want_tail) {
         TailAddP t;
         t.out = w.tq; t.o_s0 = w.tq_s0; t.o_s1 = w.tq_s1; t.o_sm = w.tq_sm;
         t.part = w.tq2; t.p_s0 = w.tq2_s0; t.p_s1 = w.tq2_s1; t.p_ts = M; t.nparts = 1; t.M = M; t.nz1 = nr.nz1;

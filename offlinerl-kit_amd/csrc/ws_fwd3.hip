@@ -16,6 +16,9 @@ namespace orl {
 
 enum { WF3_XLP = 52 };      // float pitch of a narrow-input row: three planes of 32 fp16 slots + pad (208 B: sixteen rows cover the 64 banks once)
 
+// TQ: the single-output tail folded in (two partial sums); SY: the top activation is stored (each half its 128 columns); XS: h0 is stored
+// (false: forward-only passes, WsFwdP::x0_discard).  All compile-time flavours, as in ws_fwd_kernel.
+template <bool TQ, bool SY, bool XS>
 __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32 && WS_SUB == 2, "eight waves, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
@@ -31,12 +34,13 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
   const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
   float* __restrict__ Y0g = const_cast<float*>(p.X) + z0 * p.x_s0 + z1 * p.x_s1;      // h0 is written where the plain kernel reads it
+  float* __restrict__ Yg = SY ? p.Y + z0 * p.y_s0 + z1 * p.y_s1 : nullptr;
   const float* __restrict__ X0g = p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1;
   const int ncol1 = 128 * half + 16 * wave;                              // layer-1 columns of this wave
   const int ncol0 = 32 * wave;                                           // h0 columns this wave produces
   // the h0 store of a wave whose columns belong to the other half lands in a per-workgroup scratch line (row pitch 0)
   const bool mine = (wave >> 2) == half;
-  float* __restrict__ y0b = mine ? Y0g : p.dump + (long)(((blockIdx.z * gridDim.x + blockIdx.x) * 2 + half) & (WS_DUMP_SLOTS - 1)) * WS_N;
+  float* __restrict__ y0b = !XS ? nullptr : (mine ? Y0g : p.dump + (long)(((blockIdx.z * gridDim.x + blockIdx.x) * 2 + half) & (WS_DUMP_SLOTS - 1)) * WS_N);
   const long y0p = mine ? p.x_pitch : 0;
 
   // ---- resident layer-1 fragments: lane (li, lq) supplies W1[n = ncol1 + li][k = 32 ks + 8 lq .. + 7], times ORL_WSCALE ----
@@ -72,10 +76,10 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
       ws_split8x3(a, b, b0h[cb], b0m[cb], b0l[cb]);
     }
   }
-  const float* __restrict__ twg = p.tw + z0 * p.tw_s0 + z1 * p.tw_s1;
+  const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
   if (tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }     // visible after the prologue's barriers
-  const float tbias = half == 0 ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
-  float* __restrict__ tqo = half == 0 ? p.tq + z0 * p.tq_s0 + z1 * p.tq_s1 : p.tq2 + z0 * p.tq2_s0 + z1 * p.tq2_s1;
+  const float tbias = (TQ && half == 0) ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
+  float* __restrict__ tqo = !TQ ? nullptr : (half == 0 ? p.tq + z0 * p.tq_s0 + z1 * p.tq_s1 : p.tq2 + z0 * p.tq2_s0 + z1 * p.tq2_s1);
   const long tqsm = half == 0 ? p.tq_sm : 1;
   const float inv_sc = 1.0f / ORL_WSCALE;
 
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     v = ORL_MFMA_16x16x32(b0h[cb], xah, v);
     const unsigned int nib0 = orl_relu_mask4(v);
     const int k = ncol0 + 16 * cb + 4 * lq;                              // h0 columns k .. k + 3 of row r
-    *(f32x4*)&y0b[m * y0p + k] = v;
+    if constexpr (XS) *(f32x4*)&y0b[m * y0p + k] = v;
     hx4 h, mm, l;
     orl_split4x3(v, h, mm, l);
     const int o = r * WS_PITCH + ((((k >> 3) ^ (r & 15)) << 3) | (((k >> 2) & 1) << 2));
@@ -153,15 +157,18 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     }
   };
   // the epilogue of one 16 x 16 block of h1 (row block s): bias, ReLU, tail partial sum, 4 mask bits -> LDS
-  auto epi_block = [&](const f32x4& a, int par, int s) __attribute__((always_inline)) {
+  auto epi_block = [&](const f32x4& a, int g, int par, int s) __attribute__((always_inline)) {
     const f32x4 bq = *(const f32x4*)&cst[ncol1 + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol1 + 4 * lq];
     f32x4 v = a * inv_sc + bq;
     const unsigned int nib = orl_relu_mask4(v);
-    float part = (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
+    if constexpr (SY) *(f32x4*)&Yg[((long)g * WS_ROWS + 16 * s + li) * p.y_pitch + ncol1 + 4 * lq] = v;
     nbs[(par * WS_ROWS + 16 * s + li) * WS_NBP + 4 * wave + lq] = (unsigned char)nib;
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    (qs + (par * WS_NW + wave) * WS_ROWS)[16 * s + li] = part;           // all four lq lanes hold the same sum
+    if constexpr (TQ) {
+      float part = (v[0] * twq[0] + v[1] * twq[1]) + (v[2] * twq[2] + v[3] * twq[3]);
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      (qs + (par * WS_NW + wave) * WS_ROWS)[16 * s + li] = part;         // all four lq lanes hold the same sum
+    }
   };
   auto finish = [&](int g, int par) __attribute__((always_inline)) {     // after the barrier that follows the epilogue of group g
     if (tid < WS_ROWS * 4) {                                             // thread (row, word of this half): eight nibbles -> one 32-column mask word
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
       const unsigned int hi16 = (d1 & 0xFu) | ((d1 >> 4) & 0xF0u) | ((d1 >> 8) & 0xF00u) | ((d1 >> 12) & 0xF000u);
       p.mb[z0 * p.mb_s0 + z1 * p.mb_s1 + (long)m * p.mb_g + 4 * half + wd] = lo16 | (hi16 << 16);
     }
-    if (tid >= WS_NT - WS_ROWS) {                                        // eight column-slice partial sums per row, fixed order
+    if (TQ && tid >= WS_NT - WS_ROWS) {                                  // eight column-slice partial sums per row, fixed order
       const int row = tid - (WS_NT - WS_ROWS), m = g * WS_ROWS + row;
       const float* q8 = qs + par * WS_NW * WS_ROWS + row;
       float a = tbias;
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     // first-layer blocks of the next group; 6 the narrow rows of the group after next
     auto piece = [&](int ks) __attribute__((always_inline)) {
       const int par = (it - 1) & 1;
-      if (ks < 2) epi_block(pacc[ks], par, ks);
+      if (ks < 2) epi_block(pacc[ks], g - gs, par, ks);
       else if (ks < 6) {
         const int s = (ks - 2) >> 1, cb = (ks - 2) & 1;
         if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxam, fxal);
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     if (!steady) {
       if (!first) {
 #pragma unroll
-        for (int s = 0; s < WS_SUB; ++s) epi_block(pacc[s], (it - 1) & 1, s);
+        for (int s = 0; s < WS_SUB; ++s) epi_block(pacc[s], g - gs, (it - 1) & 1, s);
       }
       // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
       if (g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
@@ -274,16 +281,32 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   }
   // drain: the last group's epilogue
 #pragma unroll
-  for (int s = 0; s < WS_SUB; ++s) epi_block(pacc[s], (it - 1) & 1, s);
+  for (int s = 0; s < WS_SUB; ++s) epi_block(pacc[s], g - gs, (it - 1) & 1, s);
   __syncthreads();
   finish(g - gs, (it - 1) & 1);
 }
 
 hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
-  static const hipError_t attr_err = hipFuncSetAttribute((const void*)ws_fwd3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ws_fwd3_lds_bytes());
+  static const hipError_t attr_err = [] {
+    const int lds = (int)ws_fwd3_lds_bytes();
+    hipError_t e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e;
+  }();
   if (attr_err != hipSuccess) return attr_err;
-  hipLaunchKernelGGL(ws_fwd3_kernel, dim3(per_z, 2, nz), dim3(WS_NT), ws_fwd3_lds_bytes(), st, p);
+  const dim3 grid(per_z, 2, nz), block(WS_NT);
+  const size_t lds = ws_fwd3_lds_bytes();
+  const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;
+  if (tq && !sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<true, false, true>), grid, block, lds, st, p);
+  else if (tq && sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<true, true, true>), grid, block, lds, st, p);
+  else if (!tq && sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<false, true, true>), grid, block, lds, st, p);
+  else if (tq && !sy && !xs) hipLaunchKernelGGL((ws_fwd3_kernel<true, false, false>), grid, block, lds, st, p);
+  else if (!tq && sy && !xs) hipLaunchKernelGGL((ws_fwd3_kernel<false, true, false>), grid, block, lds, st, p);
+  else return hipErrorInvalidValue;                 // (ws_fwd3_supported refuses every other combination)
   return hipGetLastError();
 }
 

@@ -134,7 +134,10 @@ static constexpr size_t ws_fwd3_lds_bytes() {
          2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_N;
 }
 static inline bool ws_fwd3_supported(const WsFwdP& p, int K, int N) {
-  return ws_fwd_supported(p, K, N) && ws_fwd01_supported(p) && p.tq && !p.Y && p.w_sk == 1 && !p.dmask && !p.x0_discard && p.tq2 && p.dump;
+  if (!ws_fwd_supported(p, K, N) || !ws_fwd01_supported(p) || p.w_sk != 1 || p.dmask || !p.dump) return false;
+  if (p.tq && !p.tq2) return false;
+  const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;      // the five flavours the engine's passes use (ws_fwd3.hip)
+  return (tq && !sy) || (tq && sy && xs) || (!tq && sy);
 }
 hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st);              // ws_fwd3.hip (grid.y = 2 column halves)
 
