@@ -625,9 +625,10 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0;
     if (ws_dgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, 1 << 20, ws_geo);
-      prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
-      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes, two workgroups (column halves) per net
+      const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, 1 << 20, ws_geo);
+      prof_begin(d3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * in * out + M * (double)(in + out) / 8 + 4.0 * M * (in + 1)));
+      hipError_t err = d3 ? launch_ws_dgrad3_w0(w, nz, per_z, stream) : launch_ws_dgrad_w0(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
       return 0;

@@ -11,6 +11,10 @@
 
 namespace orl {
 
+// W0 = true: dz0 stays in registers and feeds the layer-0 weight gradient (one slab per workgroup pair).  W0 = false (STORE): dz0 is written
+// to WsDgradP::C (the critic backward of an actor loss, where dz0 feeds dL/da; an actor's own backward) -- no dynamic scale then (the stored
+// values are the true ones), no X^T image, no second stage.
+template <bool W0>
 __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32, "16 columns per wave, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
@@ -26,10 +30,12 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
   const float* __restrict__ dqg = p.dq + z0 * p.dq_s0 + z1 * p.dq_s1;
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
   const float* __restrict__ wtg = p.wt + z0 * p.wt_s0 + z1 * p.wt_s1;
-  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;
+  const float* __restrict__ Xg = W0 ? p.X + z0 * p.x_s0 + z1 * p.x_s1 : nullptr;
+  float* __restrict__ Cg = W0 ? nullptr : p.C + z0 * p.c_s0 + z1 * p.c_s1;
   const int ncol0 = 128 * half + 16 * wave;
   // dq enters scaled by the run's dynamic gradient scale, the resident products by ORL_WWSCALE; dz0 carries gs * that scale into the second stage
-  const float gsc = p.gscale ? p.gscale[z0] : 1.f;
+  const float gsc = (W0 && p.gscale) ? p.gscale[z0] : 1.f;
+  const float dq_sc = W0 ? gsc : 1.0f / ORL_WWSCALE;                 // factor applied to dq when it is staged
   const float out_inv = 1.0f / (gsc * ORL_WWSCALE);
 
   // resident B' fragments: lane (li, lq) supplies B'[k = 32 ks + 8 lq + j][n = ncol0 + li] = w_tail[k] * W1[k][n]
@@ -52,19 +58,19 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
       ws_split8x3((t0 * ORL_WWSCALE) * raw[ks][0], (t1 * ORL_WWSCALE) * raw[ks][1], bh[ks], bm[ks], bl[ks]);
     }
   }
-  for (int e = tid; e < 2 * 3 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;      // rows c >= x_pitch are never written again
+  if (W0) for (int e = tid; e < 2 * 3 * 32 * WD_XP / 2; e += WS_NT) ((unsigned int*)XT)[e] = 0u;      // rows c >= x_pitch are never written again
   if (tid < 16) mlut[tid] = (u32x2_t){((tid & 1u) | ((tid & 2u) << 15)) * ORL_HX_ONE_BITS, (((tid >> 2) & 1u) | ((tid & 8u) << 13)) * ORL_HX_ONE_BITS};
   __syncthreads();
 
   // ---- staging of one row group (as in ws_dgrad_w0_kernel): thread (row r = t >> 4, half-word hw = t & 15) expands 16 mask bits; X^T elements ----
   unsigned int sm_word;
   float sx[2];
-  const int xe = WS_ROWS * p.x_pitch;                                // X elements of a row group (<= 1024)
+  const int xe = W0 ? WS_ROWS * p.x_pitch : 0;                       // X elements of a row group (<= 1024)
   int xo[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + WS_NT * i;
-    int rr = e / p.x_pitch, c = e - rr * p.x_pitch;
+    int rr = W0 ? e / (W0 ? p.x_pitch : 1) : 0, c = W0 ? e - rr * p.x_pitch : 0;
     if (e >= xe) { rr = 32; c = 0; }                                 // pad slot, never read
     xo[i] = ((c == p.in0) ? (1 << 16) : 0) | (c * WD_XP + rr);        // bit 16: the ones column (bias gradient)
   }
@@ -80,8 +86,10 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
     sm_word = (ab + row0 * p.ab_g)[vo_ab];
     sdq = (dqg + row0 * p.dq_sm)[vo_dq];
     sxw = (xb + row0 * p.xb_g)[vo_xb];
+    if (W0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sx[i] = (Xg + (long)g * xe)[vo_x[i]];
+      for (int i = 0; i < 2; ++i) sx[i] = (Xg + (long)g * xe)[vo_x[i]];
+    }
   };
   auto store_group = [&](int buf) __attribute__((always_inline)) {
     float* eo = EO + buf * (WS_ROWS + WS_NW * WS_ROWS);
@@ -92,11 +100,11 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
     hx_t* d = Ah + (long)buf * WS_ROWS * WS_PITCH + r * WS_PITCH;
     *(u32x4*)(d + (((2 * hw) ^ (r & 15)) << 3)) = c0;
     *(u32x4*)(d + (((2 * hw + 1) ^ (r & 15)) << 3)) = c1;
-    eo[tid & 31] = sdq * gsc;                                        // (replicated writes of identical values)
+    eo[tid & 31] = sdq * dq_sc;                                      // (replicated writes of identical values)
     ((unsigned int*)eo)[WS_ROWS + (tid & 7) * WS_ROWS + ((tid >> 3) & 31)] = sxw;
     hx_t* xt = XT + (long)buf * 3 * 32 * WD_XP;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2 && W0; ++i) {
       const float x = (xo[i] >> 16) ? 1.0f : sx[i];
       hx_t hh, mm, ll;
       orl_split1x3(x, hh, mm, ll);
@@ -147,41 +155,51 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
 #pragma unroll
       for (int s = 0; s < WS_SUB; ++s) acc[s] = ORL_MFMA_16x16x32(fa[s], bh[ks], acc[s]);
     }
-    // dz0 block -> three fp16 planes = B operand of the 16x16x16 MFMA; A operand = X^T rows c, columns m = 16 s + 4 lq ..
-    const hx_t* xt = XT + (long)buf * 3 * 32 * WD_XP;
+    if constexpr (!W0) {
+      // STORE: dz0 = 1[h0 > 0] (.) dq (.) acc -> C; the lane holds rows 16 s + 4 lq + r of column ncol0 + li
 #pragma unroll
-    for (int s = 0; s < WS_SUB; ++s) {
-      s16x4 xh[2], xm[2], xl[2];
+      for (int s = 0; s < WS_SUB; ++s)
 #pragma unroll
-      for (int cbk = 0; cbk < 2; ++cbk) {
-        const int o = (16 * cbk + li) * WD_XP + 16 * s + 4 * lq;
-        xh[cbk] = *(const s16x4*)&xt[o];
-        xm[cbk] = *(const s16x4*)&xt[32 * WD_XP + o];
-        xl[cbk] = *(const s16x4*)&xt[2 * 32 * WD_XP + o];
-      }
-      hx4 zh, zm, zl;
-      // (the four values split together: orl_split4x3 is 14 vector instructions, four scalar splits ~36; A/B 988 - 996 vs 1004 - 1016 us)
-      {
-        f32x4 v4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v4[r] = ((xw[s][r] >> xshift) & 1u) ? acc[s][r] * dq4[s][r] : 0.f;
-        orl_split4x3(v4, zh, zm, zl);
-      }
-      const s16x4 bzh = *(const s16x4*)&zh, bzm = *(const s16x4*)&zm, bzl = *(const s16x4*)&zl;
-#pragma unroll
-      for (int cbk = 0; cbk < 2; ++cbk) {
-        d2[cbk] = ORL_MFMA_16x16x16(xl[cbk], bzh, d2[cbk]);
-        d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzl, d2[cbk]);
-        d2[cbk] = ORL_MFMA_16x16x16(xm[cbk], bzm, d2[cbk]);
-        d2[cbk] = ORL_MFMA_16x16x16(xm[cbk], bzh, d2[cbk]);
-        d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzm, d2[cbk]);
-        d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzh, d2[cbk]);
+        for (int r = 0; r < 4; ++r)
+          Cg[((long)g * WS_ROWS + 16 * s + 4 * lq + r) * p.c_pitch + ncol0 + li] = ((xw[s][r] >> xshift) & 1u) ? acc[s][r] * dq4[s][r] : 0.f;
+    } else {
+      // dz0 block -> three fp16 planes = B operand of the 16x16x16 MFMA; A operand = X^T rows c, columns m = 16 s + 4 lq ..
+      const hx_t* xt = XT + (long)buf * 3 * 32 * WD_XP;
+  #pragma unroll
+      for (int s = 0; s < WS_SUB; ++s) {
+        s16x4 xh[2], xm[2], xl[2];
+  #pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+          const int o = (16 * cbk + li) * WD_XP + 16 * s + 4 * lq;
+          xh[cbk] = *(const s16x4*)&xt[o];
+          xm[cbk] = *(const s16x4*)&xt[32 * WD_XP + o];
+          xl[cbk] = *(const s16x4*)&xt[2 * 32 * WD_XP + o];
+        }
+        hx4 zh, zm, zl;
+        // (the four values split together: orl_split4x3 is 14 vector instructions, four scalar splits ~36; A/B 988 - 996 vs 1004 - 1016 us)
+        {
+          f32x4 v4;
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) v4[r] = ((xw[s][r] >> xshift) & 1u) ? acc[s][r] * dq4[s][r] : 0.f;
+          orl_split4x3(v4, zh, zm, zl);
+        }
+        const s16x4 bzh = *(const s16x4*)&zh, bzm = *(const s16x4*)&zm, bzl = *(const s16x4*)&zl;
+  #pragma unroll
+        for (int cbk = 0; cbk < 2; ++cbk) {
+          d2[cbk] = ORL_MFMA_16x16x16(xl[cbk], bzh, d2[cbk]);
+          d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzl, d2[cbk]);
+          d2[cbk] = ORL_MFMA_16x16x16(xm[cbk], bzm, d2[cbk]);
+          d2[cbk] = ORL_MFMA_16x16x16(xm[cbk], bzh, d2[cbk]);
+          d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzm, d2[cbk]);
+          d2[cbk] = ORL_MFMA_16x16x16(xh[cbk], bzh, d2[cbk]);
+        }
       }
     }
     if (g + gs < p.groups) store_group(buf ^ 1);
     if (g + 2 * gs < p.groups) load_group(g + 2 * gs);
     __syncthreads();
   }
+  if (!W0) return;
   // one slab per (workgroup pair): lane (li, lq) holds dW0^T[c = 16 cbk + 4 lq + r][n = ncol0 + li]
   float* wo = p.w0_out + z0 * p.o_s0 + z1 * p.o_s1 + (long)blockIdx.x * p.o_ks;
   float* bo = p.b0_out + z0 * p.o_s0 + z1 * p.ob_s1 + (long)blockIdx.x * p.o_ks;
@@ -197,7 +215,8 @@ __global__ __launch_bounds__(WS_NT) void ws_dgrad3_w0_kernel(const WsDgradP p) {
 
 hipError_t launch_ws_dgrad3_w0(WsDgradP p, int nz, int per_z, hipStream_t st) {
   p.groups = p.M / WS_ROWS;
-  hipLaunchKernelGGL(ws_dgrad3_w0_kernel, dim3(per_z, 2, nz), dim3(WS_NT), ws_dgrad3_lds_bytes(), st, p);
+  if (p.w0_out) hipLaunchKernelGGL(ws_dgrad3_w0_kernel<true>, dim3(per_z, 2, nz), dim3(WS_NT), ws_dgrad3_lds_bytes(), st, p);
+  else hipLaunchKernelGGL(ws_dgrad3_w0_kernel<false>, dim3(per_z, 2, nz), dim3(WS_NT), ws_dgrad3_lds_bytes(), st, p);
   return hipGetLastError();
 }
 

@@ -202,8 +202,8 @@ hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st);   
 static constexpr size_t ws_dgrad3_lds_bytes() {
   return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 3 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
 }
-static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {
-  return ws_dgrad_supported(p, K, N) && !p.Z && p.w0_out && !p.C;
+static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {      // from mask bits: the W0 flavour (nothing stored) or the storing one
+  return ws_dgrad_supported(p, K, N) && !p.Z && ((p.w0_out && !p.C) || (!p.w0_out && p.C)) && p.w_sn == 1;
 }
 hipError_t launch_ws_dgrad3_w0(WsDgradP p, int nz, int per_z, hipStream_t st);     // ws_dgrad3.hip
 
