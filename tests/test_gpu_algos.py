@@ -124,7 +124,7 @@ def test_many_runs_split_bf16_follows_the_oracle(algo, R):
 
 
 @pytest.mark.parametrize("R", [2, 16])
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
 def test_identical_runs_stay_bit_identical(algo, precision, R):
     """No arrival-order arithmetic anywhere in a step: the runs of one engine, given identical parameters, batches and noise, report

@@ -257,10 +257,12 @@ GRAD_NETS = {
 }
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
 def test_other_algorithms_gradients_and_parameters_at_128_runs(algo, precision):
-    """IQL / TD3+BC / EDAC at 128 runs per engine in split precision and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
+    """(precision 2: the fused forwards of IQL's / TD3+BC's two-hidden-layer nets run the three-plane kernel, everything else -- and all of EDAC,
+    whose ensemble layers have no three-plane flavour -- the exact-fp32 kernels.)
+    IQL / TD3+BC / EDAC at 128 runs per engine in split precision and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
     step 0, losses for three steps, parameters after three.  TD3+BC's actor only steps on even counts (td3bc.py:107): its gradient is
     compared on those steps."""
     R = 128
@@ -283,7 +285,7 @@ def test_other_algorithms_gradients_and_parameters_at_128_runs(algo, precision):
                     for nm in GRAD_NETS[algo]:
                         if nm + "_grads" in aux:
                             check_grads(eng, r, ids[nm], aux[nm + "_grads"], (algo, k, r, nm), precision, report,
-                                        bars=BARS_FP32_3LAYER if (precision == 0 and algo == "edac") else None)
+                                        bars=BARS_FP32_3LAYER if (precision in (0, 2) and algo == "edac") else None)
         print(f"{algo} R={R} precision {precision}, step-0 gradients vs oracle: worst max/scale {max(x[2] for x in report):.2e}, worst rel L2 {max(x[3] for x in report):.2e}")
         trainable = {nm: ids[nm] for nm in ids}
         st_cmp = {nm: ta._strip_saved(st[nm]) for nm in trainable}

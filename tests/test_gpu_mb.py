@@ -35,7 +35,7 @@ def _lead(d, R):
     return [np.stack([v] * R) for v in d]
 
 
-@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.MOPO_CASES] + [("mopo_halfcheetah", 64, 1)])
+@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.MOPO_CASES] + [("mopo_halfcheetah", 64, 1), ("mopo_halfcheetah", 64, 2)])
 def test_sac_step_matches_oracle_and_reference_mopo(case, R, precision):
     from oracle import sac as osac
     cfg, st, batches, noises = mopo_oracle_setup(case)
@@ -64,7 +64,7 @@ def test_sac_step_matches_oracle_and_reference_mopo(case, R, precision):
         eng.close()
 
 
-@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.COMBO_CASES] + [("combo_halfcheetah", 32, 1), ("combo_tiny_model", 3, 1)])
+@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.COMBO_CASES] + [("combo_halfcheetah", 32, 1), ("combo_halfcheetah", 32, 2), ("combo_tiny_model", 3, 1)])
 def test_combo_step_matches_oracle_and_reference(case, R, precision):
     from oracle import cql as ocql
     cfg, st, batches, noises = combo_oracle_setup(case)
@@ -198,7 +198,7 @@ def _mcq_engine(c, cfg, st, R, precision):
     return eng
 
 
-@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.MCQ_CASES] + [("mcq_hopper", 16, 1), ("mcq_tiny", 3, 1)])
+@pytest.mark.parametrize("case,R,precision", [(c, 1, 0) for c in synth.MCQ_CASES] + [("mcq_hopper", 16, 1), ("mcq_hopper", 16, 2), ("mcq_tiny", 3, 1)])
 def test_mcq_step_matches_oracle_and_reference(case, R, precision):
     from helpers import mcq_oracle_setup
     from oracle import mcq as omcq
