@@ -31,10 +31,13 @@
  *     2 = three fp16 planes per operand (hi + mid + lo = 33 significand bits:
  *     an fp32 operand is represented exactly) and the six products down to
  *     2^-33 with fp32 accumulation -- the arithmetic class of the fp32 MFMA at
- *     more than its rate -- in the launches that carry a many-row critic's
- *     forward / top-layer dgrad / top-layer wgrad (two-hidden-layer
- *     single-output nets from ~15 000 batched rows: CQL's critics); every other
- *     launch runs the precision-0 kernels.  The fp16 operand range of
+ *     more than its rate -- in the launches that have such a flavour: the
+ *     fused forward of a two-hidden-layer net from 4096 batched rows, the
+ *     top-layer dgrad of a single-output net, the top-layer wgrad of a
+ *     many-row critic (CQL's three dominant launches and the 256-row phases
+ *     of CQL / IQL / TD3+BC / SAC at many runs); every other launch (ensemble
+ *     layers, three-layer nets' middle layers, few-row passes) runs the
+ *     precision-0 kernels.  The fp16 operand range of
  *     precision 1 applies to those launches.
  *   - orl_step / orl_learn_n additionally return ORL_RC_UNHEALTHY (1) when the
  *     step(s) ran but a run's health flag is raised (non-finite loss or

@@ -171,8 +171,9 @@ struct Engine {
   bool use_ws32 = true;        // ... and their exact-fp32 variants at precision 0 (ORL_WS32=0: tiled fp32 kernels only)
   WsGeom ws_geo;               // workgroups per net / CUs per launch of the weight-stationary kernels (orl_config::ws_one_round, ws_cus)
   bool ws_precision_ok() const { return use_ws && (cfg.precision == 1 || use_ws32); }
-  // precision 2 = fp32-class arithmetic at more than the fp32 MFMA rate: the launches that have a three-plane flavour (the many-row critic's
-  // fused forward, its top-layer dgrad + layer-0 wgrad, its top-layer wgrad: ws_fwd3 / ws_dgrad3 / ws_wgrad_kernel<5>) multiply three fp16
+  // precision 2 = fp32-class arithmetic at more than the fp32 MFMA rate: the launches that have a three-plane flavour (the fused first +
+  // second layer forward of a two-hidden-layer net from 4096 batched rows, the top-layer dgrad from mask bits -- fused with the layer-0 wgrad or
+  // storing --, the output-stationary top-layer wgrad with derived tail gradients: ws_fwd3 / ws_dgrad3 / ws_wgrad_kernel<5>) multiply three fp16
   // planes per operand (six resp. three products), every other launch is the exact-fp32 kernel of precision 0.  The gradient scales and the
   // fp16 range watch of precision 1 apply (the planes are fp16); fp32 kernels ignore the scales.
   bool split_scales() const { return cfg.precision >= 1; }
