@@ -7,6 +7,7 @@
 // same row groups.  The A operand is the 0 / 1 ReLU mask of h1 (exact in one plane): three products per block instead of two.  The second
 // stage dW0^T += X^T dz0 multiplies three planes of X^T by three planes of dz0 (six products on v_mfma_f32_16x16x16_f16).  The two halves of
 // a (net, slab) write disjoint columns of the same split-K slab.
+// Reference: autograd of modules/critic_module.py:17-28 over nets/mlp.py:9-33 (mm / addmm / threshold_backward), as ws_dgrad.hip.
 #include "ws_device.h"
 
 namespace orl {

@@ -10,6 +10,7 @@
 // contains those columns -- the other copy goes to a scratch line through the same store instruction (a wave-uniform branch inside the row
 // loop costs the product kernel ~20 %: DESIGN.md section 8).  Each half reduces the tail over its 128 columns: half 0 writes q (with the
 // tail bias), half 1 a partial that k_tail_add folds in.  Mask words: a half writes its four words per row of h1; half 0 writes h0's.
+// Reference: nets/mlp.py:9-33 (Linear + ReLU stack), modules/critic_module.py:17-28 (the single-output tail), modules/actor_module.py:22-27.
 #include "ws_device.h"
 
 namespace orl {
