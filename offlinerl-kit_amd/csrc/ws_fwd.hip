@@ -2,6 +2,9 @@
 #ifdef WS_FWD_WAVES16      // lab: sixteen waves (16 columns each, four per SIMD, <= 128 VGPRs) for this translation unit only
 #define WS_WAVES 16
 #endif
+#ifdef WS_FWD_WAVES4       // lab: four waves (64 columns each, ONE per SIMD, up to 512 registers): half the A-fragment LDS traffic, no cross-wave overlap
+#define WS_WAVES 4
+#endif
 #include "ws_device.h"
 
 namespace orl {
@@ -164,24 +167,25 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
 
   // ---- L0: narrow-input staging (two elements per thread) and the producer of one h0 row group ----
   const int xe = L0 ? WS_ROWS * p.x0_pitch : 0;
-  int xr[2], xc[2];
-  float sx[2];
+  constexpr int XI = (WS_ROWS * 32 + WS_NT - 1) / WS_NT;              // narrow-input elements per thread (two at 512 threads)
+  int xr[XI], xc[XI];
+  float sx[XI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < XI; ++i) {
     const int e = tid + WS_NT * i;
     xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0;
     if (L0 && e >= xe) { xr[i] = 0; xc[i] = 32; }       // never read (rows are consumed as 32 columns of the 36-float pitch)
   }
   auto loadX = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
+    for (int i = 0; i < XI; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
   };
   // Split-bf16: the narrow rows are split ONCE here, by the two staging threads of an element, into a hi plane (bf16 slots 0..31 of
   // the 144-byte row) and a lo plane (slots 32..63) -- not by every wave in prod_x (eight times the same 32 vector instructions per
   // group, and vector instructions do not overlap with a SIMD's MFMAs).  Surplus threads write the pad slots 64 / 65.
   auto storeX = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XI; ++i) {
       const float x = (xc[i] == p.in0) ? 1.0f : sx[i];
       if constexpr (F32) Xl[(buf * WS_ROWS + xr[i]) * WS_XLP + xc[i]] = x;   // surplus threads: pad column 32
       else {
@@ -364,8 +368,28 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd_kernel(const WsFwdP p) {
     // staging arithmetic.  k steps 0..3: the four 16 x 16 blocks of the previous group's epilogue; 4..7: the four blocks of the next
     // group's first layer (or the four staging pieces of the plain variant).
     auto piece = [&](int ks) __attribute__((always_inline)) {
-      static_assert(WS_SUB == 2 && ((WS_CB == 2 && WS_LD == 4) || (WS_CB == 1 && WS_LD == 2)), "eight (four) pieces");
+      static_assert(WS_SUB == 2 && ((WS_CB == 2 && WS_LD == 4) || (WS_CB == 1 && WS_LD == 2) || (WS_CB == 4 && WS_LD == 8)), "eight (four, sixteen) pieces");
       const int par = (it - 1) & 1;
+      if constexpr (WS_CB == 4) {        // four waves: two pieces per k step -- 0..7 the epilogue blocks, 8..15 the first-layer blocks / staging pieces
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pc = 2 * ks + h;
+          if (pc < 8) {
+            const int s = pc >> 2, cb = pc & 3;
+            if (cb == 0) fpart = 0.f;
+            epi_block(pacc[s][cb], g - gs, par, s, cb, fpart);
+            if (cb == 3) epi_row(par, s, fpart);
+          } else if (L0) {
+            const int s = (pc - 8) >> 2, cb = (pc - 8) & 3;
+            if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxal);
+            prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxal);
+          } else {
+            store_group(buf ^ 1, stn, pc - 8, pc - 7);
+            load_piece(g + 2 * gs, stn, pc - 8);
+          }
+        }
+        return;
+      }
       if constexpr (WS_CB == 1) {        // sixteen waves: two epilogue blocks (k steps 0, 2), two first-layer blocks / staging pieces (4, 6)
         if (ks == 0 || ks == 2) {
           const int s = ks >> 1;
