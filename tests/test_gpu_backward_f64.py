@@ -33,7 +33,7 @@ from test_gpu_grads import _unpack_bits
 pytestmark = pytest.mark.gpu
 
 def bound(precision):
-    if precision == 0:
+    if precision in (0, 2):          # precision 2 (three fp16 planes where a launch has the flavour, fp32 MFMA elsewhere): the exact-fp32 constant
         return 32.0 * 2.0 ** -24
     from offlinerlkit import _engine
     return 16.0 * 2.0 ** -22 if _engine.split_bits() >= 22 else 4.0 * 2.0 ** -17
@@ -89,7 +89,7 @@ def worst_ratio(got, g, a, C, tag):
     return ratio
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_cql_three_layer_critic_backward_is_componentwise_backward_stable(precision):
     """CQL [256,256,256] (run_cql.py:31) at 32 runs: fused first + second layer forward, storing weight-stationary dgrad for the
     middle layer, tiled wgrads, weight-stationary top-layer dgrad -- every critic gradient tensor of the first and the last run."""

@@ -225,9 +225,11 @@ def test_cql_bench_configuration_gradients_and_parameters(R, precision):
         eng.close()
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_cql_three_layer_gradients(precision):
-    """reference CLI default [256,256,256] (run_cql.py:31): the middle layers go through the plain weight-stationary dgrad and the
+    """(precision 2 on a three-layer critic: the top layer's storing dgrad and its output-stationary wgrad run on three planes, the fused
+    first + second layer forward, the middle-layer launches and the third-layer forward on the exact-fp32 kernels.)
+    reference CLI default [256,256,256] (run_cql.py:31): the middle layers go through the plain weight-stationary dgrad and the
     tiled wgrads; 32 runs, split precision and exact fp32"""
     from oracle import cql as ocql
     from offlinerlkit import _engine
@@ -235,7 +237,7 @@ def test_cql_three_layer_gradients(precision):
     # with fp16 hi + lo planes the split engine lands where the exact-fp32 engine does against the fp32 numpy oracle (measured relative L2
     # 3.9e-4 on critic2's first layer in BOTH: one top-layer mask decided the other way than the oracle's BLAS); the sharp statement for
     # this path is tests/test_gpu_backward_f64.py
-    fp32_like = precision == 0 or _engine.split_bits() >= 22
+    fp32_like = precision in (0, 2) or _engine.split_bits() >= 22
     eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=precision)
     init = clone_state({k: st[k] for k in ("actor", "critic1", "critic2")})
     try:
