@@ -30,6 +30,7 @@ UNITS = {
     "ws_dgrad.hip": WS_H,
     "ws_fwd3.hip": WS_H,
     "ws_dgrad3.hip": WS_H,
+    "ws_wgrad3p.hip": WS_H,
     "ws_wgrad.hip": WS_H,
     "small_fwd.hip": ["small_fwd.h", "sample.h", "gemm.h"],
     "small_bwd.hip": ["small_bwd.h", "scalars.h", "gemm.h"],

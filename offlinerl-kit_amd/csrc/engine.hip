@@ -475,7 +475,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       // precision 2: the fused first + second layer + tail forward of a many-row single-output net has a three-plane flavour (ws_fwd3.hip);
       // its two column halves leave two tail partial sums
       bool fwd3 = false;
-      if (p3(1) && fused0 && !l.ens && ws_dump && (!want_tail || ws.count("tq_scratch"))) {
+      if (p3(1) && (fused0 || !w.X0) && !l.ens && ws_dump && (!want_tail || ws.count("tq_scratch"))) {
         bool room = true;
         if (want_tail) {
           const Mat& sc = ws.at("tq_scratch");
@@ -652,10 +652,11 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     else { w.w_sn = 1; w.w_sk = in; w.o_sr = l.layer_in(0); w.o_sc = 1; }
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo);
-      prof_begin(tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
+      const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes of dz1 and of W1
+      const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, max_slab, ws_geo);
+      prof_begin(d3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * (out + l.layer_in(0) + 1) * nz,
                  nz * (4.0 * in * out + 4.0 * M * (double)out + M * (double)in / 8 + 4.0 * M * (w0_X->pitch + 1) + 4.0 * per_z * in * (l.layer_in(0) + 1)));
-      hipError_t err = launch_ws_dgrad_w0(w, nz, per_z, stream);
+      hipError_t err = d3 ? launch_ws_dgrad3_w0(w, nz, per_z, stream) : launch_ws_dgrad_w0(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_dgrad launch ") + tag + ": " + hipGetErrorString(err));
       *w0_slabs = per_z;
@@ -837,10 +838,11 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
-      const int per_z = ws_dgrad_blocks(M, nz, max_slab, ws_geo, 1 << 20);
-      prof_begin(tag, 2.0 * M * (double)in * (out + 1 + (x_dead ? w.in0 + 1 : 0)) * nz,
+      const bool w3 = p3(4) && ws_wgrad3p_supported(w, out, in);      // precision 2: three planes of dZ and of H0, two workgroups (halves of the output rows) per slab
+      const int per_z = ws_dgrad_blocks(M, w3 ? 2 * nz : nz, max_slab, ws_geo, 1 << 20);
+      prof_begin(w3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * (out + 1 + (x_dead ? w.in0 + 1 : 0)) * nz,
                  nz * (4.0 * M * (double)((x_dead ? w.x0_pitch : in) + out) + 4.0 * per_z * out * (in + 1)));
-      hipError_t err = launch_ws_wgrad(w, nz, per_z, stream);
+      hipError_t err = w3 ? launch_ws_wgrad3p(w, nz, per_z, stream) : launch_ws_wgrad(w, nz, per_z, stream);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws_wgrad launch ") + tag + ": " + hipGetErrorString(err));
       *slabs_out = per_z;

@@ -18,8 +18,10 @@ namespace orl {
 enum { WF3_XLP = 52 };      // float pitch of a narrow-input row: three planes of 32 fp16 slots + pad (208 B: sixteen rows cover the 64 banks once)
 
 // TQ: the single-output tail folded in (two partial sums); SY: the top activation is stored (each half its 128 columns); XS: h0 is stored
-// (false: forward-only passes, WsFwdP::x0_discard).  All compile-time flavours, as in ws_fwd_kernel.
-template <bool TQ, bool SY, bool XS>
+// (false: forward-only passes, WsFwdP::x0_discard).  L0 = false: no fused first layer -- the layer's input rows come from HBM (a hidden layer
+// above the second one of a deeper net: run_cql.py:31's [256, 256, 256]) and are split into the three planes while both halves stage them.
+// All compile-time flavours, as in ws_fwd_kernel.
+template <bool TQ, bool SY, bool XS, bool L0 = true>
 __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   static_assert(WS_NW == 8 && WS_ROWS == 32 && WS_SUB == 2, "eight waves, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
   float* __restrict__ Y0g = const_cast<float*>(p.X) + z0 * p.x_s0 + z1 * p.x_s1;      // h0 is written where the plain kernel reads it
   float* __restrict__ Yg = SY ? p.Y + z0 * p.y_s0 + z1 * p.y_s1 : nullptr;
-  const float* __restrict__ X0g = p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1;
+  const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
+  const float* __restrict__ Xg = p.X + z0 * p.x_s0 + z1 * p.x_s1;           // L0 = false: the layer's input rows
   const int ncol1 = 128 * half + 16 * wave;                              // layer-1 columns of this wave
   const int ncol0 = 32 * wave;                                           // h0 columns this wave produces
   // the h0 store of a wave whose columns belong to the other half lands in a per-workgroup scratch line (row pitch 0)
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   }
   // first-layer fragments of columns ncol0 + 16 cb + li, K = 32: W0'[n][k] = W0[n][k] (k < in0), b0[n] (k == in0), 0 beyond (unscaled, as in ws_fwd)
   hx8 b0h[2], b0m[2], b0l[2];
-  {
+  if constexpr (L0) {
     const float* __restrict__ W0g = p.W0 + z0 * p.w0_s0 + z1 * p.w0_s1;
     const float* __restrict__ b0g = p.b0 + z0 * p.b0_s0 + z1 * p.b0_s1;
 #pragma unroll
@@ -85,15 +88,31 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   const float inv_sc = 1.0f / ORL_WSCALE;
 
   // ---- narrow-input staging (two elements per thread), split ONCE into three planes ----
-  const int xe = WS_ROWS * p.x0_pitch;
+  const int xe = L0 ? WS_ROWS * p.x0_pitch : 0;
   int xr[2], xc[2];
   float sx[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + WS_NT * i;
-    xr[i] = e / p.x0_pitch; xc[i] = e - xr[i] * p.x0_pitch;
-    if (e >= xe) { xr[i] = 0; xc[i] = 32; }                              // surplus threads: pad slots
+    xr[i] = L0 ? e / (L0 ? p.x0_pitch : 1) : 0; xc[i] = L0 ? e - xr[i] * p.x0_pitch : 0;
+    if (L0 && e >= xe) { xr[i] = 0; xc[i] = 32; }                        // surplus threads: pad slots
   }
+  // ---- L0 = false: staging of one [32][256] row group from HBM (thread t moves float4 #(t + 512 i), i = 0..3), split into three planes ----
+  f32x4 st0[WS_LD];
+  auto load_piece = [&](int g, int i) __attribute__((always_inline)) {
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    st0[i] = *(const f32x4*)&Xg[((long)g * WS_ROWS + r) * p.x_pitch + 4 * kq];
+  };
+  auto store_piece = [&](int buf, int i) __attribute__((always_inline)) {
+    hx_t* dh = Ah + (long)buf * 3 * WS_ROWS * WS_PITCH;
+    const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
+    hx4 h, mm, l;
+    orl_split4x3(st0[i], h, mm, l);
+    const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
+    *(hx4*)(dh + o) = h;
+    *(hx4*)(dh + WS_ROWS * WS_PITCH + o) = mm;
+    *(hx4*)(dh + 2 * WS_ROWS * WS_PITCH + o) = l;
+  };
   auto loadX = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int e = tid + WS_NT * i; sx[i] = X0g[(long)g * xe + (e < xe ? e : xe - 1)]; }   // clamped, not predicated
@@ -192,17 +211,29 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
 
   const int g0 = blockIdx.x, gs = gridDim.x;
   if (g0 >= p.groups) return;
-  for (int e = tid; e < 2 * WS_ROWS * WF3_XLP; e += WS_NT) Xl[e] = 0.f;    // columns >= x0_pitch stay zero
-  loadX(g0);
-  __syncthreads();
-  storeX(0);
-  if (g0 + gs < p.groups) loadX(g0 + gs);
-  __syncthreads();
-  produce(g0, 0, 0, 0);
-  if (g0 + gs < p.groups) storeX(1);
-  if (g0 + 2 * gs < p.groups) loadX(g0 + 2 * gs);
-  __syncthreads();
-  finish0(g0, 0);
+  if constexpr (L0) {
+    for (int e = tid; e < 2 * WS_ROWS * WF3_XLP; e += WS_NT) Xl[e] = 0.f;  // columns >= x0_pitch stay zero
+    loadX(g0);
+    __syncthreads();
+    storeX(0);
+    if (g0 + gs < p.groups) loadX(g0 + gs);
+    __syncthreads();
+    produce(g0, 0, 0, 0);
+    if (g0 + gs < p.groups) storeX(1);
+    if (g0 + 2 * gs < p.groups) loadX(g0 + 2 * gs);
+    __syncthreads();
+    finish0(g0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < WS_LD; ++i) load_piece(g0, i);
+#pragma unroll
+    for (int i = 0; i < WS_LD; ++i) store_piece(0, i);
+    if (g0 + gs < p.groups) {
+#pragma unroll
+      for (int i = 0; i < WS_LD; ++i) load_piece(g0 + gs, i);
+    }
+    __syncthreads();
+  }
 
   // Software pipeline as in ws_fwd_kernel: iteration `it` multiplies group g out of LDS buffer it & 1 while the epilogue of the PREVIOUS group and
   // the first layer of the NEXT one run, cut into pieces, in the shadow of its MFMAs.
@@ -222,10 +253,15 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
       const int par = (it - 1) & 1;
       if (ks < 2) epi_block(pacc[ks], g - gs, par, ks);
       else if (ks < 6) {
-        const int s = (ks - 2) >> 1, cb = (ks - 2) & 1;
-        if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxam, fxal);
-        prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxam, fxal);
-      } else if (ks == 6) { storeX(it & 1); loadX(g + 3 * gs); }
+        if constexpr (L0) {
+          const int s = (ks - 2) >> 1, cb = (ks - 2) & 1;
+          if (cb == 0) prod_x((it + 1) & 1, s, fxah, fxam, fxal);
+          prod_block(g + gs, buf ^ 1, (it + 1) & 1, s, cb, fxah, fxam, fxal);
+        } else {                                                         // the staging register is refilled right after it was written to LDS
+          store_piece(buf ^ 1, ks - 2);
+          load_piece(g + 2 * gs, ks - 2);
+        }
+      } else if (L0 && ks == 6) { storeX(it & 1); loadX(g + 3 * gs); }
     };
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
@@ -258,14 +294,25 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
 #pragma unroll
         for (int s = 0; s < WS_SUB; ++s) epi_block(pacc[s], g - gs, (it - 1) & 1, s);
       }
-      // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
-      if (g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
-      if (g + 2 * gs < p.groups) storeX(it & 1);
-      if (g + 3 * gs < p.groups) loadX(g + 3 * gs);
+      if constexpr (L0) {
+        // X rows of group g + gs sit in Xl[(it + 1) & 1] (written one iteration ago); rows of g + 2 gs are in registers
+        if (g + gs < p.groups) produce(g + gs, buf ^ 1, (it + 1) & 1, (it + 1) & 1);
+        if (g + 2 * gs < p.groups) storeX(it & 1);
+        if (g + 3 * gs < p.groups) loadX(g + 3 * gs);
+      } else {
+        if (g + gs < p.groups) {
+#pragma unroll
+          for (int i = 0; i < WS_LD; ++i) store_piece(buf ^ 1, i);
+        }
+        if (g + 2 * gs < p.groups) {
+#pragma unroll
+          for (int i = 0; i < WS_LD; ++i) load_piece(g + 2 * gs, i);
+        }
+      }
     }
     __syncthreads();
     if (!first) finish(g - gs, (it - 1) & 1);
-    if (steady || g + gs < p.groups) finish0(g + gs, (it + 1) & 1);
+    if (L0 && (steady || g + gs < p.groups)) finish0(g + gs, (it + 1) & 1);
 #pragma unroll
     for (int s = 0; s < WS_SUB; ++s) pacc[s] = acc[s];
   };
@@ -296,12 +343,22 @@ hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 2, nz), block(WS_NT);
   const size_t lds = ws_fwd3_lds_bytes();
   const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;
+  if (!p.X0) {                                      // no fused first layer: the input rows are staged from HBM
+    if (tq && !sy) hipLaunchKernelGGL((ws_fwd3_kernel<true, false, false, false>), grid, block, lds, st, p);
+    else if (tq && sy) hipLaunchKernelGGL((ws_fwd3_kernel<true, true, false, false>), grid, block, lds, st, p);
+    else if (!tq && sy) hipLaunchKernelGGL((ws_fwd3_kernel<false, true, false, false>), grid, block, lds, st, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (tq && !sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<true, false, true>), grid, block, lds, st, p);
   else if (tq && sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<true, true, true>), grid, block, lds, st, p);
   else if (!tq && sy && xs) hipLaunchKernelGGL((ws_fwd3_kernel<false, true, true>), grid, block, lds, st, p);

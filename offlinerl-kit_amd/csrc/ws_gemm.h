@@ -134,9 +134,11 @@ static constexpr size_t ws_fwd3_lds_bytes() {
          2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_N;
 }
 static inline bool ws_fwd3_supported(const WsFwdP& p, int K, int N) {
-  if (!ws_fwd_supported(p, K, N) || !ws_fwd01_supported(p) || p.w_sk != 1 || p.dmask || !p.dump) return false;
+  if (!ws_fwd_supported(p, K, N) || p.w_sk != 1 || p.dmask) return false;
   if (p.tq && !p.tq2) return false;
-  const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;      // the five flavours the engine's passes use (ws_fwd3.hip)
+  const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;      // the flavours the engine's passes use (ws_fwd3.hip)
+  if (!p.X0) return (tq || sy) && (p.M % WS_ROWS) == 0;                           // input rows from HBM
+  if (!ws_fwd01_supported(p) || !p.dump) return false;
   return (tq && !sy) || (tq && sy && xs) || (!tq && sy);
 }
 hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st);              // ws_fwd3.hip (grid.y = 2 column halves)
@@ -199,11 +201,13 @@ static inline int ws_dgrad_blocks(int M, int nz, int max_slab, const WsGeom& geo
 hipError_t launch_ws_dgrad_w0(WsDgradP p, int nz, int per_z, hipStream_t st);      // ws_dgrad.hip
 // precision 2 (three fp16 planes): the W0 flavour from mask bits only; a workgroup owns half of the net's columns (grid.y = 2), so the launch has
 // 2 * per_z workgroups per problem and per_z split-K slabs (ws_dgrad3.hip)
-static constexpr size_t ws_dgrad3_lds_bytes() {
-  return (size_t)2 * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 3 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
+static constexpr size_t ws_dgrad3_lds_bytes(bool plain = false) {      // mask image (plain: three planes of dz1) + X^T images (three planes) + epilogue operands
+  return (size_t)2 * (plain ? 3 : 1) * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 3 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
 }
-static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {      // from mask bits: the W0 flavour (nothing stored) or the storing one
-  return ws_dgrad_supported(p, K, N) && !p.Z && ((p.w0_out && !p.C) || (!p.w0_out && p.C)) && p.w_sn == 1;
+static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {      // from mask bits: the W0 flavour (nothing stored) or the storing one; or the plain W0 flavour
+  if (!ws_dgrad_supported(p, K, N) || p.w_sn != 1) return false;
+  if (p.Z) return true;                                                        // (ws_dgrad_supported checked w0_out / !C / xbits)
+  return (p.w0_out && !p.C) || (!p.w0_out && p.C);
 }
 hipError_t launch_ws_dgrad3_w0(WsDgradP p, int nz, int per_z, hipStream_t st);     // ws_dgrad3.hip
 
@@ -276,5 +280,12 @@ static inline bool ws_wgrad_supported(const WsWgradP& p, int K, int N) {
   return aligned16(p.wt) && !(p.wt_s0 & 3) && !(p.wt_s1 & 3);
 }
 hipError_t launch_ws_wgrad(WsWgradP p, int nz, int per_z, hipStream_t st);      // ws_wgrad.hip
+// precision 2, plain (materialised dZ) flavour: three planes of both operands; a workgroup owns half of the output rows (grid.y = 2)
+// (ws_wgrad3p.hip).  LDS: 2 buffers x {3 x [32][128] dZ planes, 3 x [32][256] H0 planes} + the ones block
+static constexpr size_t ws_wgrad3p_lds_bytes() { return (size_t)2 * (3 * WS_ROWS * 128 + 3 * WS_ROWS * WS_K) * 2 + (size_t)WS_ROWS * 16 * 2; }
+static inline bool ws_wgrad3p_supported(const WsWgradP& p, int K, int N) {
+  return p.dZ && !p.X0 && ws_wgrad_supported(p, K, N);
+}
+hipError_t launch_ws_wgrad3p(WsWgradP p, int nz, int per_z, hipStream_t st);     // ws_wgrad3p.hip
 
 }  // namespace orl

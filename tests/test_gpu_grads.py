@@ -240,6 +240,8 @@ def test_cql_three_layer_gradients(precision):
     fp32_like = precision in (0, 2) or _engine.split_bits() >= 22
     eng, cfg, st, batches, noises = tc.make_engine("cql_halfcheetah_h3", n_runs=R, precision=precision)
     init = clone_state({k: st[k] for k in ("actor", "critic1", "critic2")})
+    if precision == 2:
+        eng.profile_enable(True)
     try:
         for k, (b, n) in enumerate(zip(batches[:2], noises[:2])):
             res, aux = ocql.learn(st, cfg, b, n)
@@ -248,6 +250,9 @@ def test_cql_three_layer_gradients(precision):
                 for nm in ("actor", "critic1", "critic2"):
                     check_grads(eng, r, tc.NETS[nm], aux[nm + "_grads"], ("h3", k, r, nm), precision, bars=BARS_FP32_3LAYER if fp32_like else None)
         check_params(eng, (0, R - 1), {nm: tc.NETS[nm] for nm in ("actor", "critic1", "critic2")}, st, 2, "cql_h3", init, rel_bar=0.15)     # measured 8.2 % (one top-layer mask flip reaches both layers below)
+        if precision == 2:          # all six many-row launches of the three-layer critic ran their three-plane flavours
+            tags = {row["name"] for row in eng.profile_table()}
+            assert {"critic.fwd1@p3", "critic.fwd2@p3", "critic.bwd.dgrad2@p3", "critic.bwd.dgrad1@p3", "critic.bwd.wgrad2@p3", "critic.bwd.wgrad1@p3"} <= tags, sorted(tags)
     finally:
         eng.close()
 
