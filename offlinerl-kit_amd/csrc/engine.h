@@ -173,8 +173,9 @@ struct Engine {
   bool ws_precision_ok() const { return use_ws && (cfg.precision == 1 || use_ws32); }
   // precision 2 = fp32-class arithmetic at more than the fp32 MFMA rate: the launches that have a three-plane flavour (the fused first +
   // second layer forward of a two-hidden-layer net from 4096 batched rows, the top-layer dgrad from mask bits -- fused with the layer-0 wgrad or
-  // storing --, the output-stationary top-layer wgrad with derived tail gradients: ws_fwd3 / ws_dgrad3 / ws_wgrad_kernel<5>) multiply three fp16
-  // planes per operand (six resp. three products), every other launch is the exact-fp32 kernel of precision 0.  The gradient scales and the
+  // storing --, the output-stationary top-layer wgrad with derived tail gradients, and for deeper nets the forward of a layer fed from HBM and
+  // the plain dgrad / wgrad of a middle layer: ws_fwd3 / ws_dgrad3 / ws_wgrad_kernel<5> / ws_wgrad3p) multiply three fp16 planes per operand
+  // (six resp. three products), every other launch is the exact-fp32 kernel of precision 0.  The gradient scales and the
   // fp16 range watch of precision 1 apply (the planes are fp16); fp32 kernels ignore the scales.
   bool split_scales() const { return cfg.precision >= 1; }
   int mm_prec() const { return cfg.precision == 1 ? 1 : 0; }       // precision of a launch without a three-plane flavour
