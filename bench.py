@@ -637,6 +637,10 @@ def main():
                     d = float(np.median(timed_rate(es, n_side, 0.6)))
                     fp32_class["by_runs"].append(dict(runs_per_gpu=r_side, engines_per_gpu=1, value=r_side * n_side / d, ms_per_step=d / n_side * 1e3))
                     es[0].close()
+                # ... and the reference CLI's default depth [256,256,256] (run_cql.py:31) at 128 runs: all six many-row launches on three planes
+                h3 = other_config("cql_h3", local_rank, 2, 128, 0.8)
+                h3.pop("roofline", None)
+                fp32_class["cql_h3"] = h3
             others = {a: other_config(a, local_rank, args.precision, 128, 0.8) for a in ("td3bc", "iql", "edac", "cql_h3")}
             api = api_record(local_rank, args.precision, 128, 1000, ds)
             # the drop-in number: CQLPolicy exactly as run_cql.py:80-128 builds it -- one policy, no set_engine_options (n_runs 1, the product's
