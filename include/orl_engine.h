@@ -32,11 +32,12 @@
  *     an fp32 operand is represented exactly) and the six products down to
  *     2^-33 with fp32 accumulation -- the arithmetic class of the fp32 MFMA at
  *     more than its rate -- in the launches that have such a flavour: the
- *     weight-stationary forward / dgrad / wgrad launches of nn.Linear nets
- *     with 256-wide hidden layers from 4096 batched rows (CQL's dominant
- *     launches at two and three hidden layers, the 256-row phases of CQL /
- *     IQL / TD3+BC / SAC at many runs); every other launch (ensemble layers,
- *     tiled and few-row passes) runs the precision-0 kernels.  The fp16 operand range of
+ *     weight-stationary forward / dgrad / wgrad launches of nets with
+ *     256-wide hidden layers from 4096 batched rows (CQL's dominant launches
+ *     at two and three hidden layers, the 256-row phases of CQL / IQL /
+ *     TD3+BC / SAC at many runs, the forwards and dgrads of EDAC's ensemble
+ *     critics); every other launch (tiled and few-row passes) runs the
+ *     precision-0 kernels.  The fp16 operand range of
  *     precision 1 applies to those launches.
  *   - orl_step / orl_learn_n additionally return ORL_RC_UNHEALTHY (1) when the
  *     step(s) ran but a run's health flag is raised (non-finite loss or

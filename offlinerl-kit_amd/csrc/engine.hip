@@ -475,7 +475,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
       // precision 2: the fused first + second layer + tail forward of a many-row single-output net has a three-plane flavour (ws_fwd3.hip);
       // its two column halves leave two tail partial sums
       bool fwd3 = false;
-      if (p3(1) && (fused0 || !w.X0) && !l.ens && ws_dump && (!want_tail || ws.count("tq_scratch"))) {
+      if (p3(1) && (fused0 || !w.X0) && ws_dump && (!want_tail || ws.count("tq_scratch"))) {
         bool room = true;
         if (want_tail) {
           const Mat& sc = ws.at("tq_scratch");

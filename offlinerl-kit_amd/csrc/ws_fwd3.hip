@@ -51,10 +51,19 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   hx8 bh[8], bm[8], bl[8];
   {
     f32x4 raw[8][2];
+    if (p.w_sk == 1) {                                                   // nn.Linear (out, in): k-contiguous rows
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const float* src = Wg + (long)(ncol1 + li) * p.w_sn + (32 * ks + 8 * lq);
-      raw[ks][0] = *(const f32x4*)src; raw[ks][1] = *(const f32x4*)(src + 4);
+      for (int ks = 0; ks < 8; ++ks) {
+        const float* src = Wg + (long)(ncol1 + li) * p.w_sn + (32 * ks + 8 * lq);
+        raw[ks][0] = *(const f32x4*)src; raw[ks][1] = *(const f32x4*)(src + 4);
+      }
+    } else {                                                             // EnsembleLinear (in, out): eight strided loads per fragment, once per workgroup
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float* src = Wg + (long)(ncol1 + li) * p.w_sn + (long)(32 * ks + 8 * lq) * p.w_sk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { raw[ks][0][j] = src[(long)j * p.w_sk]; raw[ks][1][j] = src[(long)(4 + j) * p.w_sk]; }
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) ws_split8x3(raw[ks][0] * ORL_WSCALE, raw[ks][1] * ORL_WSCALE, bh[ks], bm[ks], bl[ks]);

@@ -134,7 +134,7 @@ static constexpr size_t ws_fwd3_lds_bytes() {
          2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_N;
 }
 static inline bool ws_fwd3_supported(const WsFwdP& p, int K, int N) {
-  if (!ws_fwd_supported(p, K, N) || p.w_sk != 1 || p.dmask) return false;
+  if (!ws_fwd_supported(p, K, N) || p.dmask) return false;
   if (p.tq && !p.tq2) return false;
   const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;      // the flavours the engine's passes use (ws_fwd3.hip)
   if (!p.X0) return (tq || sy) && (p.M % WS_ROWS) == 0;                           // input rows from HBM
@@ -205,7 +205,7 @@ static constexpr size_t ws_dgrad3_lds_bytes(bool plain = false) {      // mask i
   return (size_t)2 * (plain ? 3 : 1) * WS_ROWS * WS_PITCH * 2 + (size_t)2 * 3 * 32 * WD_XP * 2 + (size_t)2 * (WS_ROWS + WS_NW * WS_ROWS) * 4;
 }
 static inline bool ws_dgrad3_supported(const WsDgradP& p, int K, int N) {      // from mask bits: the W0 flavour (nothing stored) or the storing one; or the plain W0 flavour
-  if (!ws_dgrad_supported(p, K, N) || p.w_sn != 1) return false;
+  if (!ws_dgrad_supported(p, K, N)) return false;
   if (p.Z) return true;                                                        // (ws_dgrad_supported checked w0_out / !C / xbits)
   return (p.w0_out && !p.C) || (!p.w0_out && p.C);
 }

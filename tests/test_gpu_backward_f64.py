@@ -137,7 +137,7 @@ def edac_gamma_f64(g, eta, K, B):
     return c / nk - g * ((g * c).sum(axis=2, keepdims=True) / (nk * nk * safe)), grad_loss
 
 
-@pytest.mark.parametrize("precision", [1, 0])
+@pytest.mark.parametrize("precision", [1, 0, 2])
 def test_edac_critic_backward_and_diversity_sweep_are_componentwise_backward_stable(precision):
     """EDAC, walker2d shapes (K = 10, [256,256,256], eta = 5) at 128 runs: on the engine's own (obs | act) rows, dL_TD/dq and packed
     masks, float64 gives (i) the action gradients g = dQ_k/da of the unit-seed backward (``edac.delta*``), (ii) gamma from the

@@ -267,8 +267,8 @@ GRAD_NETS = {
 @pytest.mark.parametrize("precision", [1, 0, 2])
 @pytest.mark.parametrize("algo", ["iql", "td3bc", "edac"])
 def test_other_algorithms_gradients_and_parameters_at_128_runs(algo, precision):
-    """(precision 2: the fused forwards of IQL's / TD3+BC's two-hidden-layer nets run the three-plane kernel, everything else -- and all of EDAC,
-    whose ensemble layers have no three-plane flavour -- the exact-fp32 kernels.)
+    """(precision 2: the weight-stationary forwards / dgrads of every algorithm's 256-wide nets run the three-plane kernels -- EDAC's ensemble
+    critics included --, the tiled launches the exact-fp32 kernels.)
     IQL / TD3+BC / EDAC at 128 runs per engine in split precision and in exact fp32 (full-size fixtures' shapes): gradients of every trainable net at
     step 0, losses for three steps, parameters after three.  TD3+BC's actor only steps on even counts (td3bc.py:107): its gradient is
     compared on those steps."""
