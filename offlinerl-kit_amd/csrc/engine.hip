@@ -689,8 +689,9 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
     w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
     if (ws_fwd_supported(w, out, in)) {
-      prof_begin(tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
-      hipError_t err = launch_ws_fwd(w, nz, stream, ws_geo);
+      const bool f3 = p3(2) && ws_fwd3_supported(w, out, in);       // precision 2: three planes of dz and of the weights (column halves)
+      prof_begin(f3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
+      hipError_t err = f3 ? launch_ws_fwd3(w, nz, ws_blocks_per_problem(M / WS_ROWS, 2 * nz, 10, 1 << 20, ws_geo), stream) : launch_ws_fwd(w, nz, stream, ws_geo);
       prof_end();
       if (err != hipSuccess) return fail(std::string("ws dgrad launch ") + tag + ": " + hipGetErrorString(err));
       return 0;

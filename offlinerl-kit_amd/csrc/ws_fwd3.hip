@@ -20,9 +20,12 @@ enum { WF3_XLP = 52 };      // float pitch of a narrow-input row: three planes o
 // TQ: the single-output tail folded in (two partial sums); SY: the top activation is stored (each half its 128 columns); XS: h0 is stored
 // (false: forward-only passes, WsFwdP::x0_discard).  L0 = false: no fused first layer -- the layer's input rows come from HBM (a hidden layer
 // above the second one of a deeper net: run_cql.py:31's [256, 256, 256]) and are split into the three planes while both halves stage them.
+// DG (with L0 = false, SY): plain dgrad mode -- Y = (X B^T) (.) mask with X a materialised gradient (times the run's dynamic scale while it is
+// staged), B the weights viewed transposed, no bias / ReLU / mask emission; the mask of the receiving activation comes from its packed bits.
 // All compile-time flavours, as in ws_fwd_kernel.
-template <bool TQ, bool SY, bool XS, bool L0 = true>
+template <bool TQ, bool SY, bool XS, bool L0 = true, bool DG = false>
 __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
+  static_assert(!DG || (!TQ && SY && !L0), "gradient mode: rows from HBM, result stored, no tail");
   static_assert(WS_NW == 8 && WS_ROWS == 32 && WS_SUB == 2, "eight waves, 32-row groups");
   extern __shared__ __attribute__((aligned(16))) float ws_smem[];
   hx_t* Ah = (hx_t*)ws_smem;                                           // [buf][hi, mid, lo][row][WS_PITCH]
@@ -35,7 +38,9 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   const int half = blockIdx.y;
   const int z = blockIdx.z, z0 = z / p.nz1, z1 = z - z0 * p.nz1;
   const float* __restrict__ Wg = p.W + z0 * p.w_s0 + z1 * p.w_s1;
-  const float* __restrict__ bg = p.bias + z0 * p.b_s0 + z1 * p.b_s1;
+  const float* __restrict__ bg = DG ? nullptr : p.bias + z0 * p.b_s0 + z1 * p.b_s1;
+  const unsigned int* __restrict__ dmg = DG ? p.dmask + z0 * p.dm_s0 + z1 * p.dm_s1 : nullptr;
+  const float a_sc = (DG && p.gscale) ? p.gscale[z0] : 1.f;          // gradient mode: the staged rows carry the run's dynamic gradient scale
   float* __restrict__ Y0g = const_cast<float*>(p.X) + z0 * p.x_s0 + z1 * p.x_s1;      // h0 is written where the plain kernel reads it
   float* __restrict__ Yg = SY ? p.Y + z0 * p.y_s0 + z1 * p.y_s1 : nullptr;
   const float* __restrict__ X0g = L0 ? p.X0 + z0 * p.x0_s0 + z1 * p.x0_s1 : nullptr;
@@ -90,11 +95,11 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     }
   }
   const float* __restrict__ twg = TQ ? p.tw + z0 * p.tw_s0 + z1 * p.tw_s1 : bg;
-  if (tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }     // visible after the prologue's barriers
+  if (!DG && tid < WS_N) { cst[tid] = bg[tid]; cst[WS_N + tid] = twg[tid]; }     // visible after the prologue's barriers
   const float tbias = (TQ && half == 0) ? (p.tb + z0 * p.tb_s0 + z1 * p.tb_s1)[0] : 0.f;
   float* __restrict__ tqo = !TQ ? nullptr : (half == 0 ? p.tq + z0 * p.tq_s0 + z1 * p.tq_s1 : p.tq2 + z0 * p.tq2_s0 + z1 * p.tq2_s1);
   const long tqsm = half == 0 ? p.tq_sm : 1;
-  const float inv_sc = 1.0f / ORL_WSCALE;
+  const float inv_sc = 1.0f / (ORL_WSCALE * a_sc);
 
   // ---- narrow-input staging (two elements per thread), split ONCE into three planes ----
   const int xe = L0 ? WS_ROWS * p.x0_pitch : 0;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     hx_t* dh = Ah + (long)buf * 3 * WS_ROWS * WS_PITCH;
     const int idx = tid + WS_NT * i, r = idx >> 6, kq = idx & 63;
     hx4 h, mm, l;
-    orl_split4x3(st0[i], h, mm, l);
+    if (DG) orl_split4x3(st0[i] * a_sc, h, mm, l); else orl_split4x3(st0[i], h, mm, l);
     const int o = r * WS_PITCH + ((((kq >> 1) ^ (r & 15)) << 3) | ((kq & 1) << 2));
     *(hx4*)(dh + o) = h;
     *(hx4*)(dh + WS_ROWS * WS_PITCH + o) = mm;
@@ -187,6 +192,15 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
   };
   // the epilogue of one 16 x 16 block of h1 (row block s): bias, ReLU, tail partial sum, 4 mask bits -> LDS
   auto epi_block = [&](const f32x4& a, int g, int par, int s) __attribute__((always_inline)) {
+    if constexpr (DG) {                                                  // gradient epilogue: ReLU mask of the receiving activation from its packed bits
+      const long m = (long)g * WS_ROWS + 16 * s + li;
+      const unsigned int nib = dmg[m * p.dm_g + (ncol1 >> 5)] >> ((ncol1 & 31) + 4 * lq);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? a[r] * inv_sc : 0.f;
+      *(f32x4*)&Yg[m * p.y_pitch + ncol1 + 4 * lq] = v;
+      return;
+    }
     const f32x4 bq = *(const f32x4*)&cst[ncol1 + 4 * lq], twq = *(const f32x4*)&cst[WS_N + ncol1 + 4 * lq];
     f32x4 v = a * inv_sc + bq;
     const unsigned int nib = orl_relu_mask4(v);
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(WS_NT) void ws_fwd3_kernel(const WsFwdP p) {
     }
   };
   auto finish = [&](int g, int par) __attribute__((always_inline)) {     // after the barrier that follows the epilogue of group g
-    if (tid < WS_ROWS * 4) {                                             // thread (row, word of this half): eight nibbles -> one 32-column mask word
+    if (!DG && tid < WS_ROWS * 4) {                                      // thread (row, word of this half): eight nibbles -> one 32-column mask word
       const int row = tid >> 2, wd = tid & 3, m = g * WS_ROWS + row;
       const unsigned int* nb = (const unsigned int*)(nbs + (par * WS_ROWS + row) * WS_NBP + 8 * wd);
       const unsigned int d0 = nb[0], d1 = nb[1];
@@ -355,12 +369,17 @@ hipError_t launch_ws_fwd3(WsFwdP p, int nz, int per_z, hipStream_t st) {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<true, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)ws_fwd3_kernel<false, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     return e;
   }();
   if (attr_err != hipSuccess) return attr_err;
   const dim3 grid(per_z, 2, nz), block(WS_NT);
   const size_t lds = ws_fwd3_lds_bytes();
   const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;
+  if (p.dmask) {                                    // plain dgrad mode
+    hipLaunchKernelGGL((ws_fwd3_kernel<false, true, false, false, true>), grid, block, lds, st, p);
+    return hipGetLastError();
+  }
   if (!p.X0) {                                      // no fused first layer: the input rows are staged from HBM
     if (tq && !sy) hipLaunchKernelGGL((ws_fwd3_kernel<true, false, false, false>), grid, block, lds, st, p);
     else if (tq && sy) hipLaunchKernelGGL((ws_fwd3_kernel<true, true, false, false>), grid, block, lds, st, p);

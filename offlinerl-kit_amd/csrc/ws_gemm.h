@@ -134,7 +134,8 @@ static constexpr size_t ws_fwd3_lds_bytes() {
          2 * WS_ROWS * WS_NBP + sizeof(float) * 2 * WS_N;
 }
 static inline bool ws_fwd3_supported(const WsFwdP& p, int K, int N) {
-  if (!ws_fwd_supported(p, K, N) || p.dmask) return false;
+  if (!ws_fwd_supported(p, K, N)) return false;
+  if (p.dmask) return p.Y != nullptr;                                             // plain dgrad mode (ws_fwd_supported: no tail, no fused first layer, 8 mask words per row)
   if (p.tq && !p.tq2) return false;
   const bool tq = p.tq != nullptr, sy = p.Y != nullptr, xs = !p.x0_discard;      // the flavours the engine's passes use (ws_fwd3.hip)
   if (!p.X0) return (tq || sy) && (p.M % WS_ROWS) == 0;                           // input rows from HBM
