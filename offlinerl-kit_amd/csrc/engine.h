@@ -178,8 +178,13 @@ struct Engine {
   // (six resp. three products), every other launch is the exact-fp32 kernel of precision 0.  The gradient scales and the
   // fp16 range watch of precision 1 apply (the planes are fp16); fp32 kernels ignore the scales.
   bool split_scales() const { return cfg.precision >= 1; }
-  int mm_prec() const { return cfg.precision == 1 ? 1 : 0; }       // precision of a launch without a three-plane flavour
-  int p3_mask = 7;                                                  // ORL_P3: bit 0 forward, 1 dgrad, 2 wgrad (lab: single kernels against their fp32 twins)
+  // precision of a tiled launch (gemm.h: P_F32 / P_SPLIT / P_SPLIT3) and the exact-fp32 flag of a weight-stationary / few-rows launch WITHOUT
+  // a three-plane flavour.  The tiled kernel has the three-plane multiply as a template flavour (ORL_P3 bit 3), but precision 2 keeps its tiled
+  // launches on the exact-fp32 MFMA by default: they are staging- and latency-bound, three planes cost them LDS space and split work and
+  // measured SLOWER than fp32 (128 runs: CQL 33.2k -> 30.8k, IQL 137.8k -> 132.1k, TD3+BC 184.7k -> 179.5k, EDAC 14.1k -> 13.5k).
+  int mm_prec() const { return cfg.precision == 2 ? ((p3_mask & 8) ? 2 : 0) : cfg.precision; }
+  int ws_f32() const { return cfg.precision != 1; }
+  int p3_mask = 7;                                                  // ORL_P3: bit 0 forward, 1 dgrad, 2 wgrad, (3: tiled launches, off by default) (lab: single kernels against their fp32 twins)
   bool p3(int bit) const { return cfg.precision == 2 && (p3_mask & bit); }
   float* ws_dump = nullptr;                                         // precision 2: scratch lines of ws_fwd3_kernel (WS_DUMP_SLOTS x WS_N floats)
   // split precision: per-run dynamic power-of-two scale of the gradient matrices of the backward pass being enqueued (k_grad_scale);

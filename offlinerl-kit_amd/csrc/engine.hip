@@ -444,7 +444,7 @@ int Engine::linear_fwd(const Mat& X, int M, const NetRef& nr, int layer, const M
     w.bias = nr.base + l.b_off[layer]; w.b_s0 = nr.rs; w.b_s1 = l.b_ms[layer];
     w.Y = Y.p; w.y_s0 = Y.rs; w.y_s1 = Y.cs; w.y_pitch = Y.pitch;
     w.mb = Y.bits; w.mb_s0 = Y.brs; w.mb_s1 = Y.bcs; w.mb_g = Y.bg;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32();
     const bool want_tail = tail_out && tail_fused && layer == l.L - 1 && l.out_dim == 1;
     if (want_tail) {
       w.tw = nr.base + l.w_off[l.L]; w.tw_s0 = nr.rs; w.tw_s1 = l.w_ms[l.L];
@@ -565,6 +565,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.a_dscale = cur_gscale; p.b_scale = ORL_WSCALE;     // split precision: A = a gradient matrix of the current backward pass, B = weights
+  if (mm_prec() == P_SPLIT3) p.a_scale = ORL_GSCALE3;   // three planes: 2^5 more headroom above fp16's 2^-24 grid for the matrix's small elements
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
   p.a_sr = dy.m.pitch; p.a_sk = 1;
   if (dy.rank1) {
@@ -598,7 +599,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     float* g = grads + nr.g_off;
     w.w0_out = g + l.w_off[0]; w.b0_out = g + l.b_off[0];
     w.o_s0 = (long)max_slab * P_train; w.o_s1 = l.w_ms[0]; w.ob_s1 = l.b_ms[0]; w.o_ks = P_train; w.o_sr = l.layer_in(0); w.o_sc = 1;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32(); w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
       const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes, two workgroups (column halves) per slab
       const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, max_slab, ws_geo);
@@ -623,7 +624,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     w.W = nr.base + l.w_off[layer]; w.w_s0 = nr.rs; w.w_s1 = l.w_ms[layer];
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.C = dX.p; w.c_s0 = dX.rs; w.c_s1 = dX.cs; w.c_pitch = dX.pitch;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32();
     if (ws_dgrad_supported(w, out, in)) {
       const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes, two workgroups (column halves) per net
       const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, 1 << 20, ws_geo);
@@ -650,7 +651,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     // nn.Linear keeps (out, in)-major weights, EnsembleLinear (in, out)-major ones: the same holds for the gradient slabs
     if (l.ens) { w.w_sn = out; w.w_sk = 1; w.o_sr = 1; w.o_sc = l.layer_out(0); }
     else { w.w_sn = 1; w.w_sk = in; w.o_sr = l.layer_in(0); w.o_sc = 1; }
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32(); w.gscale = cur_gscale;
     if (ws_dgrad_supported(w, out, in)) {
       const bool d3 = p3(2) && ws_dgrad3_supported(w, out, in);      // precision 2: three planes of dz1 and of W1
       const int per_z = ws_dgrad_blocks(M, d3 ? 2 * nz : nz, max_slab, ws_geo);
@@ -687,7 +688,7 @@ int Engine::linear_dgrad(const DY& dy, int M, const NetRef& nr, int layer, int c
     if (l.ens) { w.w_sn = out; w.w_sk = 1; } else { w.w_sn = 1; w.w_sk = in; }
     w.Y = dX.p; w.y_s0 = dX.rs; w.y_s1 = dX.cs; w.y_pitch = dX.pitch;
     w.dmask = maskH->bits; w.dm_s0 = maskH->brs; w.dm_s1 = maskH->bcs; w.dm_g = maskH->bg;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32(); w.gscale = cur_gscale;
     if (ws_fwd_supported(w, out, in)) {
       const bool f3 = p3(2) && ws_fwd3_supported(w, out, in);       // precision 2: three planes of dz and of the weights (column halves)
       prof_begin(f3 ? (std::string(tag) + "@p3").c_str() : tag, 2.0 * M * (double)in * out * nz, nz * (4.0 * M * out + 4.0 * in * out + 4.0 * M * in + M * (double)in / 8));
@@ -764,6 +765,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
   GemmP p;
   memset(&p, 0, sizeof(p));
   p.a_dscale = cur_gscale; p.b_dscale = x_dscale;      // split precision: A = dY^T of the current backward pass; B = X (an activation, or a gradient-like matrix with its own scale)
+  if (mm_prec() == P_SPLIT3) { p.a_scale = ORL_GSCALE3; if (x_dscale) p.b_scale = ORL_GSCALE3; }
   p.A = {dy.m.p, dy.m.rs, dy.m.cs};
   p.a_sr = 1; p.a_sk = dy.m.pitch;
   if (out == 1 && dy.m.pitch == 1 && !dy.rank1) p.a_sr = 4;   // a [1 x M] row vector: k-contiguous, any row stride -> vector loads
@@ -807,7 +809,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
       w.b1 = nr.base + l.b_off[layer]; w.b1_s0 = nr.rs; w.b1_s1 = l.b_ms[layer];
     } else { w.H1 = dy.m.p; w.h1_s0 = dy.m.rs; w.h1_s1 = dy.m.cs; w.h1_pitch = dy.m.pitch; }
     w.dwt = g + l.w_off[l.L]; w.dbt = g + l.b_off[l.L]; w.o_s1wt = l.w_ms[l.L]; w.o_s1bt = l.b_ms[l.L];
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32(); w.gscale = cur_gscale;
     w.np3 = p3(4) && derived;                                        // precision 2: three planes of G = dq (.) h0 (ws_wgrad_kernel<5>)
     if (ws_wgrad_supported(w, out, in)) {
       const int per_z = ws_dgrad_blocks(M, nz, ws_wgrad_slab_cap, ws_geo, 1 << 20);      // one round: the slab write + derived tail gradients per workgroup cost more than idle CUs (4 slabs at 192 nets: 540 us either way, and Adam then reads 4 slabs)
@@ -837,7 +839,7 @@ int Engine::linear_wgrad(const DY& dy, const Mat& X, int M, const NetRef& nr, in
     }
     w.dW = g + l.w_off[layer]; w.db = g + l.b_off[layer];
     w.o_s0 = g_rs; w.o_s1w = l.w_ms[layer]; w.o_s1b = l.b_ms[layer]; w.o_ks = P_train;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = this->mm_prec() == 0; w.gscale = cur_gscale;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = this->ws_f32(); w.gscale = cur_gscale;
     if (ws_wgrad_supported(w, out, in)) {
       const bool w3 = p3(4) && ws_wgrad3p_supported(w, out, in);      // precision 2: three planes of dZ and of H0, two workgroups (halves of the output rows) per slab
       const int per_z = ws_dgrad_blocks(M, w3 ? 2 * nz : nz, max_slab, ws_geo, 1 << 20);
@@ -933,7 +935,7 @@ int Engine::mlp_forward(const Mat& X, int M, const NetRef& nr, std::vector<Mat>&
       w.H1 = hs[1].p; w.h1_s0 = hs[1].rs; w.h1_s1 = hs[1].cs;
     }
     w.OUT = out.p; w.o_s0 = out.rs; w.o_s1 = out.cs; w.o_pitch = out.pitch; w.out_dim = l.out_dim;
-    w.M = M; w.nz1 = nr.nz1; w.f32 = mm_prec() == 0;
+    w.M = M; w.nz1 = nr.nz1; w.f32 = ws_f32();
     if (fuse_small && jobs && jobs_done && njobs >= 1 && njobs <= 3 && nr.nz1 == 1 && l.out_dim == 2 * ad && ad <= 8 && out.pitch == l.out_dim) {
       w.njobs = njobs; w.A = ad;
       for (int i = 0; i < njobs; ++i) w.job[i] = jobs[i];
@@ -983,7 +985,7 @@ int Engine::mlp_qgrad(const Mat& X, int M, const NetRef& nr, const Mat& q, const
   w.bt = nr.base + l.b_off[2]; w.bt_s0 = nr.rs; w.bt_s1 = l.b_ms[2];
   w.OUT = q.p; w.o_s0 = q.rs; w.o_s1 = q.cs; w.o_pitch = q.pitch; w.out_dim = 1;
   w.G = G.p; w.g_s0 = G.rs; w.g_s1 = G.cs; w.g_pitch = G.pitch; w.gc0 = gc0; w.gn = gn;
-  w.M = M; w.nz1 = nr.nz1; w.f32 = mm_prec() == 0;
+  w.M = M; w.nz1 = nr.nz1; w.f32 = ws_f32();
   if (!small_fwd_supported(w)) return 0;
   const int nz = R * nr.nz1;
   if (lab_slot < 4) w.lab_clk = (unsigned long long*)(aloss_part + (long)R * SB_MAXGROUPS * 2) + 16 + 12 * lab_slot++;
@@ -1882,7 +1884,7 @@ int orl_profile_query(orl_engine* h, int idx, char* name, int name_cap, double* 
 //  mode 4: rank-1 wgrad  A_eff[k,m] = A[k,m]>0 ? v0[k]*v1[m] : 0 ; output like mode 2
 int orl_debug_gemm(int cfg, int mode, int M, int N, int K, const float* A, const float* Bh, const float* v0, const float* v1,
                    float* C, int ksplit, int precision) {
-  if (precision != 0 && precision != 1) return fail("precision must be 0 or 1");
+  if (precision < 0 || precision > 2) return fail("precision must be 0, 1 or 2");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device");
   hipStream_t st = nullptr;

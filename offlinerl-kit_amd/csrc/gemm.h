@@ -62,6 +62,10 @@ typedef hx_t hx8 __attribute__((ext_vector_type(8)));
 // static operand scales of the split multiply (powers of two; 1 in the bf16 build would do as well, they are exact either way)
 #define ORL_WSCALE 64.0f             // weight matrices (|w| < 1023): U(+-1/16)-sized weights land at O(1)
 #define ORL_WWSCALE 256.0f           // products w_tail[k] * W1[k][n] held by ws_dgrad_w0 (|.| < 255)
+// tiled three-plane launches (P_SPLIT3): static factor on top of a gradient matrix's dynamic scale (which puts the seed's largest element at
+// 8 .. 16 and leaves 2^12 for growth through the layers): the third plane of an element 2^-9 below the largest one would otherwise sit on
+// fp16's 2^-24 grid with two or three bits.  2^5 keeps 2^7 of growth headroom below 65504.
+#define ORL_GSCALE3 32.0f
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
@@ -171,7 +175,8 @@ __device__ __forceinline__ unsigned int orl_mask4(const f32x4& z) {
 // precision of the multiply: P_F32 = v_mfma_f32_16x16x4_f32 (exact fp32);  P_SPLIT = every operand (times its power-of-two scale) split
 // into hi = half(x), lo = half(x - hi) while it is staged into LDS, product = lo*hi + hi*lo + hi*hi on the 16-bit MFMA with fp32
 // accumulation (22 significand bits per operand, 3/16 of the fp32 MFMA cycles), the scales divided out of the accumulators
-enum { P_F32 = 0, P_SPLIT = 1, P_BF16X3 = P_SPLIT };
+// P_SPLIT3 (precision 2): three planes per operand (hi + mid + lo = an fp32 value exactly), six products -- fp32-class arithmetic
+enum { P_F32 = 0, P_SPLIT = 1, P_BF16X3 = P_SPLIT, P_SPLIT3 = 2 };
 
 enum { PA_PLAIN = 0, PA_RANK1 = 1, PA_RANK1B = 2 };                    // prologue on A elements (RANK1B: ReLU mask from packed bits)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -253,7 +258,7 @@ struct GemmCfg {
   static constexpr int PITCH_H = TK + 8;                       // bf16 planes: row stride (TK+8)*2 B, 16-B aligned
   static constexpr int LDS_FLOATS = 2 * (TM + TN) * PITCH;
   static constexpr size_t lds_bytes(int prec) {
-    return prec == P_F32 ? sizeof(float) * LDS_FLOATS : (size_t)2 /*buf*/ * 2 /*hi,lo*/ * (TM + TN) * PITCH_H * 2;
+    return prec == P_F32 ? sizeof(float) * LDS_FLOATS : (size_t)2 /*buf*/ * (prec == P_SPLIT3 ? 3 : 2) /*planes*/ * (TM + TN) * PITCH_H * 2;
   }
   // LDS the epilogue may use for the staged C tile: the operand buffers, or (when those already limit a CU to one
   // workgroup) the whole 160 KB

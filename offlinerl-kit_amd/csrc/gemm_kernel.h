@@ -189,6 +189,32 @@ struct TileLoader {
     }
   }
 
+  // three planes (P_SPLIT3): hi at lds_h, mid ROWS*PITCH further, lo 2*ROWS*PITCH further
+  __device__ inline void store_split3(hx_t* __restrict__ lds_h, int tid, float sc) const {
+    hx_t* lds_m = lds_h + ROWS * PITCH;
+    hx_t* lds_l = lds_m + ROWS * PITCH;
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      if (!EXACT && tid + i * NT >= NSLOTS) break;
+      const float* o = &reg[i * SLOT_ELEMS];
+      if (LMODE == L_SCALAR) {
+        hx_t hh, mm, ll; orl_split1x3(o[0] * sc, hh, mm, ll);
+        lds_h[loff[i]] = hh; lds_m[loff[i]] = mm; lds_l[loff[i]] = ll;
+      } else if (LMODE == L_VECK || LMODE == L_VECKU) {
+        hx4 h, m, l;
+        orl_split4x3((f32x4){o[0] * sc, o[1] * sc, o[2] * sc, o[3] * sc}, h, m, l);
+        *(hx4*)(lds_h + loff[i]) = h; *(hx4*)(lds_m + loff[i]) = m; *(hx4*)(lds_l + loff[i]) = l;
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          hx4 h, m, l;
+          orl_split4x3((f32x4){o[rr * 4] * sc, o[rr * 4 + 1] * sc, o[rr * 4 + 2] * sc, o[rr * 4 + 3] * sc}, h, m, l);
+          *(hx4*)(lds_h + loff[i] + rr * PITCH) = h; *(hx4*)(lds_m + loff[i] + rr * PITCH) = m; *(hx4*)(lds_l + loff[i] + rr * PITCH) = l;
+        }
+      }
+    }
+  }
+
   __device__ inline void store(float* __restrict__ lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
@@ -216,7 +242,8 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
   float* As = smem;
   float* Bs = smem + 2 * TM * PITCH;
   hx_t* Ah = (hx_t*)smem;
-  hx_t* Bh = Ah + 2 * 2 * TM * PITCH;
+  constexpr int NPL = (PREC == P_SPLIT3) ? 3 : 2;                       // 16-bit planes per operand
+  hx_t* Bh = Ah + 2 * NPL * TM * PITCH;
 
   const int tid = threadIdx.x;
   const int z = p.zmajor ? (int)(blockIdx.z * 8 + (blockIdx.x & 7)) : (int)blockIdx.z;
@@ -289,6 +316,7 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
 
   auto store_chunk = [&](int buf) {
     if (PREC == P_F32) { la.store(As + buf * TM * PITCH, tid); lb.store(Bs + buf * TN * PITCH, tid); }
+    else if (PREC == P_SPLIT3) { la.store_split3(Ah + buf * 3 * TM * PITCH, tid, sc_a); lb.store_split3(Bh + buf * 3 * TN * PITCH, tid, sc_b); }
     else { la.store_split(Ah + buf * 2 * TM * PITCH, tid, sc_a); lb.store_split(Bh + buf * 2 * TN * PITCH, tid, sc_b); }
   };
   if (kc_begin < kc_end) {
@@ -322,6 +350,50 @@ __global__ __launch_bounds__(CFG::NT) void gemm16_kernel(const GemmP p) {
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int a = 0; a < MA; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, fa[a][s], accb[a], 0, 0, 0);
+        }
+      }
+    } else if (PREC == P_SPLIT3) {
+      // three planes per operand: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi (smallest terms first)
+      const hx_t* ah = Ah + buf * 3 * TM * PITCH;
+      const hx_t* am = ah + TM * PITCH;
+      const hx_t* al = am + TM * PITCH;
+      const hx_t* bh = Bh + buf * 3 * TN * PITCH;
+      const hx_t* bm = bh + TN * PITCH;
+      const hx_t* bl = bm + TN * PITCH;
+#pragma unroll
+      for (int kk = 0; kk < TK; kk += 32) {
+        hx8 fah[MA], fam[MA], fal[MA], fbh[NB], fbm[NB], fbl[NB];
+#pragma unroll
+        for (int a = 0; a < MA; ++a) {
+          const int o = (wrow0 + a * 16 + li) * PITCH + kk + 8 * lq;
+          fah[a] = *(const hx8*)&ah[o]; fam[a] = *(const hx8*)&am[o]; fal[a] = *(const hx8*)&al[o];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int o = (wcol0 + b * 16 + li) * PITCH + kk + 8 * lq;
+          fbh[b] = *(const hx8*)&bh[o]; fbm[b] = *(const hx8*)&bm[o]; fbl[b] = *(const hx8*)&bl[o];
+        }
+#pragma unroll
+        for (int a = 0; a < MA; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            acc[a][b] = ORL_MFMA_16x16x32(fbl[b], fah[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbh[b], fal[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbm[b], fam[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbm[b], fah[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbh[b], fam[a], acc[a][b]);
+            acc[a][b] = ORL_MFMA_16x16x32(fbh[b], fah[a], acc[a][b]);
+          }
+        if (EPI == E_WGRAD && want_bias) {
+          hx8 one;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) one[j] = (hx_t)1.0f;
+#pragma unroll
+          for (int a = 0; a < MA; ++a) {
+            accb[a] = ORL_MFMA_16x16x32(one, fal[a], accb[a]);
+            accb[a] = ORL_MFMA_16x16x32(one, fam[a], accb[a]);
+            accb[a] = ORL_MFMA_16x16x32(one, fah[a], accb[a]);
+          }
         }
       }
     } else {
@@ -686,6 +758,10 @@ static inline hipError_t launch_cfg(const GemmP& p, int la, int lb, int nz, hipS
 template <class CFG, int PA, int PB, int EPI>
 static inline hipError_t launch_cfg_prec(const GemmP& p, int la, int lb, int nz, hipStream_t st, int prec) {
   if (prec == P_BF16X3) return launch_cfg<CFG, PA, PB, EPI, P_BF16X3>(p, la, lb, nz, st);
+  if (prec == P_SPLIT3) {
+    if constexpr (CFG::lds_bytes(P_SPLIT3) <= (size_t)160 * 1024) return launch_cfg<CFG, PA, PB, EPI, P_SPLIT3>(p, la, lb, nz, st);
+    else return launch_cfg<CfgSq, PA, PB, EPI, P_SPLIT3>(p, la, lb, nz, st);      // (the 256 x 128 tile's three-plane buffers exceed the LDS: 128 x 128 instead)
+  }
   return launch_cfg<CFG, PA, PB, EPI, P_F32>(p, la, lb, nz, st);
 }
 
@@ -719,9 +795,11 @@ hipError_t launch_gemm_rank1_bits(int cfg, const GemmP& p, int nz, hipStream_t s
 #define ORL_RB(CFG, LB, PREC) launch_inst<CFG, L_VECK, LB, PA_RANK1B, PB_PLAIN, EPI, PREC>(p, nz, st)
   if (cfg == CFG_SQ) {
     if (prec == P_BF16X3) return lb == L_BLK4 ? ORL_RB(CfgSq, L_BLK4, P_BF16X3) : ORL_RB(CfgSq, L_VECK, P_BF16X3);
+    if (prec == P_SPLIT3) return lb == L_BLK4 ? ORL_RB(CfgSq, L_BLK4, P_SPLIT3) : ORL_RB(CfgSq, L_VECK, P_SPLIT3);
     return lb == L_BLK4 ? ORL_RB(CfgSq, L_BLK4, P_F32) : ORL_RB(CfgSq, L_VECK, P_F32);
   }
   if (prec == P_BF16X3) return lb == L_BLK4 ? ORL_RB(CfgBig, L_BLK4, P_BF16X3) : ORL_RB(CfgBig, L_VECK, P_BF16X3);
+  if (prec == P_SPLIT3) return lb == L_BLK4 ? ORL_RB(CfgBig, L_BLK4, P_SPLIT3) : ORL_RB(CfgBig, L_VECK, P_SPLIT3);
   return lb == L_BLK4 ? ORL_RB(CfgBig, L_BLK4, P_F32) : ORL_RB(CfgBig, L_VECK, P_F32);
 #undef ORL_RB
 }

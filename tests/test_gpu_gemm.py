@@ -72,38 +72,43 @@ def test_wgrad_with_bias_column_and_splitk(cfg, shape, ksplit):
     _close(got[M * N:], dz.sum(0))
 
 
+@pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL, CFG_MID | 16])
 @pytest.mark.parametrize("shape", [(64, 256, 32), (70, 40, 23), (256, 256, 256), (300, 257, 129), (513, 256, 260)])
-def test_split_bf16_forward_dgrad(cfg, shape):
-    """precision=1: hi/lo bf16 split, 3 MFMA products, fp32 accumulate -> ~16 mantissa bits per operand."""
+def test_split_bf16_forward_dgrad(cfg, shape, precision):
+    """precision=1: hi/lo split, 3 MFMA products, fp32 accumulate (the bar dates from the bf16 planes: ~16 mantissa bits per operand);
+    precision=2: three fp16 planes, 6 products -- held to the exact-fp32 kernel's summation-order tolerance."""
     from offlinerlkit._engine import debug_gemm
+    tol = 2e-4 if precision == 1 else 2e-5
     M, N, K = shape
     rng = np.random.RandomState(M + 3 * N + 7 * K)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = rng.standard_normal((N, K)).astype(np.float32)
     b = rng.standard_normal(N).astype(np.float32)
-    got = debug_gemm(cfg, 0, A, W, b, M=M, N=N, K=K, precision=1).reshape(M, N)
-    _close(got, np.maximum(A.astype(np.float64) @ W.T.astype(np.float64) + b, 0), tol=2e-4)
+    got = debug_gemm(cfg, 0, A, W, b, M=M, N=N, K=K, precision=precision).reshape(M, N)
+    _close(got, np.maximum(A.astype(np.float64) @ W.T.astype(np.float64) + b, 0), tol=tol)
     Wm = rng.standard_normal((K, N)).astype(np.float32)
     H = rng.standard_normal((M, N)).astype(np.float32)
-    got = debug_gemm(cfg, 1, A, Wm, H, M=M, N=N, K=K, precision=1).reshape(M, N)
-    _close(got, (A.astype(np.float64) @ Wm.astype(np.float64)) * (H > 0), tol=2e-4)
+    got = debug_gemm(cfg, 1, A, Wm, H, M=M, N=N, K=K, precision=precision).reshape(M, N)
+    _close(got, (A.astype(np.float64) @ Wm.astype(np.float64)) * (H > 0), tol=tol)
 
 
+@pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("cfg", [CFG_BIG, CFG_MID, CFG_SMALL, CFG_TALL])
 @pytest.mark.parametrize("shape", [(64, 64, 512), (256, 23, 1000), (1, 256, 300), (256, 256, 1024)])
-def test_split_bf16_wgrad(cfg, shape):
+def test_split_bf16_wgrad(cfg, shape, precision):
     from offlinerlkit._engine import debug_gemm
+    tol = 2e-4 if precision == 1 else 2e-5
     M, N, K = shape
     rng = np.random.RandomState(M * 13 + N + K * 2)
     dY = rng.standard_normal((K, M)).astype(np.float32)
     X = rng.standard_normal((K, N)).astype(np.float32)
-    got = debug_gemm(cfg, 2, dY, X, ksplit=4, M=M, N=N, K=K, precision=1)
-    _close(got[:M * N].reshape(M, N), dY.T.astype(np.float64) @ X.astype(np.float64), tol=2e-4)
-    _close(got[M * N:], dY.astype(np.float64).sum(0), tol=2e-4)
+    got = debug_gemm(cfg, 2, dY, X, ksplit=4, M=M, N=N, K=K, precision=precision)
+    _close(got[:M * N].reshape(M, N), dY.T.astype(np.float64) @ X.astype(np.float64), tol=tol)
+    _close(got[M * N:], dY.astype(np.float64).sum(0), tol=tol)
     H = rng.standard_normal((K, M)).astype(np.float32)
     dq = rng.standard_normal(K).astype(np.float32)
     w = rng.standard_normal(M).astype(np.float32)
-    got = debug_gemm(cfg, 4, H, X, dq, w, ksplit=4, M=M, N=N, K=K, precision=1)
+    got = debug_gemm(cfg, 4, H, X, dq, w, ksplit=4, M=M, N=N, K=K, precision=precision)
     dz = ((H > 0) * np.outer(dq, w)).astype(np.float64)
-    _close(got[:M * N].reshape(M, N), dz.T @ X.astype(np.float64), tol=2e-4)
+    _close(got[:M * N].reshape(M, N), dz.T @ X.astype(np.float64), tol=tol)
