@@ -103,6 +103,16 @@ struct Engine {
   orl_config cfg;
   int dev = 0;
   hipStream_t stream = nullptr;
+  // A second stream for launches that do not depend on each other (CQL: the target critics' forward next to the critics' forward, both fed
+  // by the actor pass before them): fork_side() makes `stream` the side stream until fork_main(); fork_join() makes the main stream wait for
+  // the side work.  Inside a graph capture the three calls become a fork / join of the captured graph.  OFF by default (ORL_FORK=1 enables it):
+  // measured 10 us per step SLOWER at 1 - 8 runs per engine -- a fork / join of graph branches costs more than the 12 us launch it hides.
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool fork_on = false, forked = false;
+  int fork_side();
+  void fork_main() { if (forked) std::swap(stream, side_stream); }
+  int fork_join();
   int R = 1, B = 0, N = 0, od = 0, ad = 0, OP = 0, AP = 0, XP = 0, L = 0, K = 2;
   NetLayout lay[ORL_NUM_NETS];
   float* arena = nullptr;      // [R][P_train] then [R][P_tgt]

@@ -205,6 +205,10 @@ Engine::~Engine() {
   }
   for (auto& e : ev_pool) hipEventDestroy(e);
   for (void* p : allocs) hipFree(p);
+  if (forked) std::swap(stream, side_stream);
+  if (ev_fork) hipEventDestroy(ev_fork);
+  if (ev_join) hipEventDestroy(ev_join);
+  if (side_stream) hipStreamDestroy(side_stream);
   if (stream) hipStreamDestroy(stream);
 }
 
@@ -277,6 +281,21 @@ void Engine::prof_begin(const char* name, double flops, double bytes) {
 void Engine::prof_end() {
   if (!prof_on) return;
   hipEventRecord(prof.back().b, stream);
+}
+
+int Engine::fork_side() {
+  forked = false;
+  if (!fork_on || prof_on) return 0;                 // (the per-tag timing of a profiled run brackets launches on the main stream)
+  if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(side_stream, ev_fork, 0) != hipSuccess) return fail("fork: event");
+  std::swap(stream, side_stream);
+  forked = true;
+  return 0;
+}
+int Engine::fork_join() {
+  if (!forked) return 0;
+  forked = false;                                    // (fork_main() has swapped the streams back: side_stream holds the side work)
+  if (hipEventRecord(ev_join, side_stream) != hipSuccess || hipStreamWaitEvent(stream, ev_join, 0) != hipSuccess) return fail("join: event");
+  return 0;
 }
 
 float* Engine::gscale_slot() {
@@ -1167,6 +1186,10 @@ int Engine::init(const orl_config& c) {
     return fail("actor_dropout: supported for IQL only (run_iql.py --dropout_rate), 0 < p < 1");
   if (build_layouts(c, lay, net_off, net_is_target, &P_train, &P_tgt)) return -1;
   ORL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  ORL_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+  ORL_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  ORL_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  { const char* f = getenv("ORL_FORK"); if (f) fork_on = atoi(f) != 0; }
   R = c.n_runs; B = c.batch_size; od = c.obs_dim; ad = c.act_dim;
   N = c.num_repeat_actions > 0 ? c.num_repeat_actions : 1;
   OP = rup(od, 4); AP = rup(ad, 4); XP = rup(od + ad, 4); L = c.n_hidden;
